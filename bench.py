@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the flow-step hot path: grid-point-updates/s of one 3D Navier-Stokes step.
+
+  python bench.py --gpus N --steps K --warmup W
+
+N = 1: 512^3 navier_stokes step on one MI355X (BASELINE.json metric).  N > 1 (launched by
+torch.distributed.run, one rank per GPU): the same 512^3 grid cut into N z-slabs (strong
+scaling: total work fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "sopht-mpi_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+# Algorithmic bytes per grid point of one f32 navier_stokes step, counted operator by
+# operator along the reference's own call sequence (423 scalar-field passes of 4 B).
+ALG_BYTES_PER_POINT_STEP = 1692.0
+
+
+def synthetic_vorticity(position_field, real_t, seed=0, nblobs=8, sigma=0.05):
+    """Smooth compact vorticity: Gaussian blobs with random amplitudes at random centres in
+    [0.3, 0.7]^3 (of each axis range).  Built from 1D factors, so 512^3 costs seconds."""
+    rng = np.random.default_rng(seed)
+    x = position_field[0][0, 0, :].astype(np.float64)
+    y = position_field[1][0, :, 0].astype(np.float64)
+    z = position_field[2][:, 0, 0].astype(np.float64)
+    shape = position_field.shape[1:]
+    out = np.zeros((3,) + shape, dtype=real_t)
+    for _ in range(nblobs):
+        c = rng.uniform(0.3, 0.7, 3)
+        amp = rng.uniform(-1, 1, 3)
+        gx = np.exp(-((x - c[0]) ** 2) / (2 * sigma**2))
+        gy = np.exp(-((y - c[1]) ** 2) / (2 * sigma**2))
+        gz = np.exp(-((z - c[2]) ** 2) / (2 * sigma**2))
+        blob = (gz[:, None, None] * gy[None, :, None] * gx[None, None, :]).astype(real_t)
+        for k in range(3):
+            out[k] += real_t(amp[k]) * blob
+    return out
+
+
+def roofline_from_profile(prof):
+    """Roofline entry for the dominant kernel: the profiler slot with the largest total time
+    inside the timed region (HIP events recorded on the library's own stream).  achieved =
+    algorithmic bytes per launch / average launch duration.  traffic (HBM bytes from PMC
+    counters) needs separate rocprofv3 --pmc passes; see profiles/."""
+    if not prof:
+        return None
+    name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = rec["ms"] / rec["launches"]
+    achieved = rec["alg_bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+            "alg_bytes_per_launch": rec["alg_bytes"] / rec["launches"]}
+
+
+def cpu_baseline(grid, steps):
+    """The oracle (CPU restatement, not sopht-mpi itself) timed on this box's host cores."""
+    from oracle import poisson as opoisson
+    from oracle.flow_3d import FlowSimulator3D
+
+    workers = min(16, os.cpu_count() or 1)
+    opoisson._WORKERS = workers
+    sim = FlowSimulator3D((grid,) * 3, 1.0, 1e-3, flow_type="navier_stokes", real_t=np.float32)
+    sim.vorticity_field[...] = synthetic_vorticity(sim.position_field, np.float32)
+    sim.compute_flow_velocity()
+    dt = float(sim.compute_stable_timestep())
+    sim.time_step(dt)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.time_step(dt)
+    el = time.perf_counter() - t0
+    return {
+        "value": grid**3 * steps / el,
+        "unit": "grid-point-updates/s",
+        "cores": workers,
+        "kind": "port",
+        "sample": f"{steps} navier_stokes steps on a {grid}^3 grid (numpy stencils on 1 core, scipy.fft on "
+                  f"{workers} threads); restatement of the reference algorithm, not sopht-mpi itself",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--poisson", default=None, choices=[None, "rocfft", "pruned"])
+    ap.add_argument("--cpu-grid", type=int, default=128)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+
+    from sopht_mpi_amd import _lib
+    from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
+    from sopht_mpi_amd.world import get_world
+
+    world = get_world()
+    rank = world.rank
+    n, real_t = args.grid, np.float32
+    sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=1e-3,
+                                   flow_type="navier_stokes", real_t=real_t, ghost_size=2, penalty_zone_width=2,
+                                   poisson_backend=args.poisson)
+    sim.vorticity_field[...] = synthetic_vorticity(sim.position_field, real_t)
+    sim.compute_flow_velocity(free_stream_velocity=None)
+    dt = float(sim.compute_stable_timestep())  # CFL 0.1, fixed over the timed region
+
+    for _ in range(args.warmup):
+        sim.time_step(dt=dt)
+    sim.ctx.sync()
+    world.barrier()
+    _lib.call("smi_prof_enable", sim.ctx.handle, 1)
+    _lib.call("smi_prof_reset", sim.ctx.handle)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.time_step(dt=dt)
+    sim.ctx.sync()
+    world.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = world.allreduce(elapsed, "max")
+    prof = _lib.prof_collect(sim.ctx)
+    _lib.call("smi_prof_enable", sim.ctx.handle, 0)
+    max_vort = float(sim.get_max_vorticity())
+    if not np.isfinite(max_vort):
+        raise SystemExit("bench: vorticity became non-finite")
+
+    if rank != 0:
+        return
+    ms = 1e3 * elapsed / args.steps
+    value = n**3 * args.steps / elapsed
+    out = {
+        "metric": "grid-point-updates/sec per flow step (512^3 3D)",
+        "value": value,
+        "unit": "grid-point-updates/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"3D {n}^3 navier_stokes flow step (rotational advection + diffusion + penalise + "
+                        "3 unbounded Poisson solves + curl), ghost 2, seeded Gaussian-blob vorticity",
+            "grid": [n, n, n],
+            "partition": "1 GPU" if args.gpus == 1 else f"{args.gpus} z-slabs, RCCL",
+            "poisson_backend": sim.unbounded_poisson_solver.backend,
+            "step_hbm_frac_alg": ALG_BYTES_PER_POINT_STEP * value / args.gpus / 1e9 / HBM_PEAK_GBS,
+        },
+    }
+    out["roofline"] = roofline_from_profile(prof)
+    out["kernels"] = {k: {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"],
+                          "alg_GBps": v["alg_bytes"] / v["ms"] / 1e6 if v["ms"] > 0 else None}
+                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_steps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,214 @@
+/*
+ * sophtmi.h -- C ABI of libsophtmi.so: the MI355X (gfx950) implementation of the
+ * sopht-mpi Eulerian flow-step hot path.
+ *
+ * The reference (fankiat/sopht-mpi) is pure Python and has no FFI boundary; its
+ * boundary is a Python calling convention (generator functions returning operator
+ * closures).  Every entry point below names the reference operator it replaces as
+ * file:line relative to the reference tree.  Conventions:
+ *
+ *   - every function returns 0 on success, non-zero on failure; the message of the
+ *     last failure on the calling thread is smi_last_error().  Nothing throws.
+ *   - all field pointers are DEVICE pointers obtained from smi_malloc.  Fields are
+ *     C-ordered [z][y][x] arrays of the context's real type INCLUDING `ghost` ghost
+ *     layers per side, vector fields are (3, z, y, x) with component 0 = x, exactly
+ *     the reference's local arrays (flow_simulators_mpi_3d.py:170-196).
+ *   - real scalars cross the ABI as double and are rounded to the context's real
+ *     type inside (pass the reference's real_t(...) value; the round trip is exact).
+ *   - calls enqueue on the context's HIP stream and return; smi_sync waits.  Entry
+ *     points that return a value to the host (reductions, downloads) synchronise.
+ *   - one context = one GPU = one z-slab of the global grid (the reference's
+ *     rank_distribution=(0,1,1) slab mode, utils/mpi_utils_3d.py:32-66).
+ */
+#ifndef SOPHTMI_H
+#define SOPHTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smi_ctx smi_ctx;
+typedef struct smi_poisson smi_poisson;
+
+enum { SMI_F32 = 0, SMI_F64 = 1 };
+/* Poisson back ends */
+enum { SMI_POISSON_ROCFFT = 0, SMI_POISSON_PRUNED = 1 };
+/* Laplacian filter types (laplacian_filter_mpi_3d.py:387-397) */
+enum { SMI_FILTER_MULTIPLICATIVE = 0, SMI_FILTER_CONVOLUTION = 1 };
+/* delta kernels (EulerianLagrangianGridCommunicatorMPI3D.py:81-97) */
+enum { SMI_DELTA_COSINE = 0, SMI_DELTA_PESKIN = 1 };
+
+const char* smi_last_error(void);
+int smi_version(void);
+int smi_device_count(int* count);
+
+/* ---- context / topology -------------------------------------------------------
+ * Replaces MPIConstruct3D + MPIGhostCommunicator3D construction
+ * (utils/mpi_utils_3d.py:14-83, 118-139).  nz/ny/nx: LOCAL interior sizes of this
+ * slab; rank/nranks: position in the z-slab decomposition (physical z boundaries
+ * are rank 0's low face and rank nranks-1's high face; y and x faces are always
+ * physical).  dtype: SMI_F32 / SMI_F64. */
+int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost,
+                   int rank, int nranks);
+int smi_ctx_destroy(smi_ctx* ctx);
+int smi_sync(smi_ctx* ctx);
+
+/* RCCL communicator over the slab ranks.  unique_id: the 128-byte ncclUniqueId made
+ * by smi_comm_unique_id on rank 0 and broadcast by the host launcher.  Replaces
+ * MPI.COMM_WORLD.Create_cart (utils/mpi_utils_3d.py:64-66). */
+int smi_comm_unique_id(void* out128);
+int smi_comm_init(smi_ctx* ctx, const void* unique_id128);
+/* Host-side transport hook.  When set, every halo exchange (kind 0) and ghost sum
+ * (kind 1) the library needs is handed to `cb` instead of RCCL; the callback moves whole
+ * ghost planes with smi_planes_d2h / smi_planes_h2d.  For ranks that share one GPU.
+ * Replaces nothing in the reference (its transport is always MPI). */
+typedef int (*smi_exchange_cb)(void* user, void* field, int ncomp, int kind);
+int smi_set_exchange_callback(smi_ctx* ctx, smi_exchange_cb cb, void* user);
+/* allreduce of n host doubles over the slab ranks through RCCL; op: 0 = sum, 1 = min,
+ * 2 = max.  Replaces grid.allreduce (flow_simulators_mpi_3d.py:448, 465-467, 475). */
+int smi_allreduce_f64(smi_ctx* ctx, double* host_inout, int n, int op);
+
+/* ---- in-library kernel timing (HIP events on the context's stream) -----------------
+ * No counterpart in the reference (it has no timing code).  Slots are named kernels or
+ * kernel groups; bytes = algorithmic bytes summed over the launches. */
+int smi_prof_enable(smi_ctx* ctx, int on);
+int smi_prof_reset(smi_ctx* ctx);
+int smi_prof_num_slots(void);
+int smi_prof_get(smi_ctx* ctx, int slot, char* name64, int64_t* launches, double* total_ms,
+                 double* alg_bytes);
+
+/* ---- memory ---------------------------------------------------------------- */
+int smi_malloc(smi_ctx* ctx, size_t bytes, void** dptr);
+int smi_free(smi_ctx* ctx, void* dptr);
+int smi_memcpy_h2d(smi_ctx* ctx, void* dst, const void* src, size_t bytes);
+int smi_memcpy_d2h(smi_ctx* ctx, void* dst, const void* src, size_t bytes);
+int smi_memcpy_d2d(smi_ctx* ctx, void* dst, const void* src, size_t bytes);
+int smi_memset_zero(smi_ctx* ctx, void* dptr, size_t bytes);
+
+/* ---- halo exchange ------------------------------------------------------------
+ * MPIGhostCommunicator3D.exchange_scalar_field_init / exchange_vector_field_init +
+ * exchange_finalise (utils/mpi_utils_3d.py:756-842, 1125-1142) for z-slabs: the first /
+ * last `ghost` interior planes go to the neighbour's ghost planes.  Whole padded planes
+ * travel (they are contiguous), so the y/x ghost columns of the z ghost planes carry the
+ * neighbour's values instead of stale local ones; no interior cell reads them.
+ * No-op on a single rank.  Needs smi_comm_init when nranks > 1. */
+int smi_halo_exchange(smi_ctx* ctx, void* field, int ncomp);
+/* Host-staged transport, for ranks that share one GPU (tests) or have no RCCL
+ * communicator: copy `nplanes` whole z planes starting at padded plane index z0 of every
+ * component to / from a host buffer laid out [ncomp][nplanes][py][px]; accumulate != 0
+ * adds instead of overwriting (ghost sum). */
+int smi_planes_d2h(smi_ctx* ctx, const void* field, int ncomp, int z0, int nplanes, void* host);
+int smi_planes_h2d(smi_ctx* ctx, void* field, int ncomp, int z0, int nplanes, const void* host,
+                   int accumulate);
+
+/* ---- elementwise operators (sopht elementwise kernels; call sites cited) -------- */
+/* gen_set_fixed_val_pyst_kernel_3d, flow_simulators_mpi_3d.py:303-305, 422-424 */
+int smi_set_fixed_val(smi_ctx* ctx, void* field, int ncomp, const double* vals);
+/* gen_add_fixed_val_pyst_kernel_3d, flow_simulators_mpi_3d.py:309-318 */
+int smi_add_fixed_val(smi_ctx* ctx, void* sum_field, const void* field, int ncomp, const double* vals);
+/* gen_elementwise_sum_pyst_kernel_3d, diffusion_timestep_mpi_3d.py:57-59 */
+int smi_elementwise_sum(smi_ctx* ctx, void* sum_field, const void* f1, const void* f2, int ncomp);
+/* gen_elementwise_copy_pyst_kernel_3d, laplacian_filter_mpi_3d.py:279 */
+int smi_elementwise_copy(smi_ctx* ctx, void* dst, const void* src, int ncomp);
+/* gen_elementwise_saxpby_pyst_kernel_3d, laplacian_filter_mpi_3d.py:313-319 */
+int smi_elementwise_saxpby(smi_ctx* ctx, void* sum_field, const void* f1, double a, const void* f2,
+                           double b, int ncomp);
+/* gen_elementwise_cross_product_pyst_kernel_3d, flow_simulators_mpi_3d.py:267-269, 396-401 */
+int smi_cross_product(smi_ctx* ctx, void* result, const void* f1, const void* f2);
+
+/* ---- stencil operators ----------------------------------------------------------- */
+/* gen_diffusion_flux_pyst_mpi_kernel_3d, stencil_ops_3d/diffusion_flux_mpi_3d.py:10-228 */
+int smi_diffusion_flux(smi_ctx* ctx, void* flux, const void* field, double prefactor, int ncomp);
+/* gen_diffusion_timestep_euler_forward_pyst_mpi_kernel_3d, diffusion_timestep_mpi_3d.py:11-92.
+ * `flux` is ONE scalar scratch field, reused per component as in the reference. */
+int smi_diffusion_timestep(smi_ctx* ctx, void* field, void* flux, double nu_dt_by_dx2, int ncomp);
+/* gen_update_vorticity_from_velocity_forcing_pyst_mpi_kernel_3d,
+ * update_vorticity_from_velocity_forcing_mpi_3d.py:9-178 */
+int smi_update_vorticity_from_velocity_forcing(smi_ctx* ctx, void* vorticity, void* forcing,
+                                               double prefactor);
+/* gen_curl_pyst_mpi_kernel_3d, curl_mpi_3d.py:10-196 */
+int smi_curl(smi_ctx* ctx, void* curl, void* field, double prefactor);
+/* gen_divergence_pyst_mpi_kernel_3d, divergence_mpi_3d.py:10-200 */
+int smi_divergence(smi_ctx* ctx, void* divergence, void* field, double inv_dx);
+/* gen_penalise_field_boundary_pyst_mpi_kernel_3d, penalise_field_boundary_mpi_3d.py:9-269.
+ * fac_lo/fac_hi: host arrays, per axis x,y,z: 3 * (ghost+width) sine factors for the low
+ * band (index 0 = outermost cell) and for the high band (index 0 = first cell of the band). */
+int smi_penalise_boundary(smi_ctx* ctx, void* field, int ncomp, int width, const double* fac_lo,
+                          const double* fac_hi);
+/* gen_laplacian_filter_mpi_kernel_3d, laplacian_filter_mpi_3d.py:14-421 */
+int smi_laplacian_filter(smi_ctx* ctx, void* field, int ncomp, void* filter_flux_buffer,
+                         void* field_buffer, int order, int filter_type);
+/* gen_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d,
+ * advection_timestep_mpi_3d.py:12-95 (+ advection_flux_mpi_3d.py:8-195) */
+int smi_advection_timestep_eno3(smi_ctx* ctx, void* field, void* flux, void* velocity,
+                                double dt_by_dx, int ncomp);
+
+/* ---- reductions (flow_simulators_mpi_3d.py:426-476); LOCAL values, the host
+ *      launcher combines ranks (allreduce MIN / MAX / SUM) -------------------------- */
+int smi_reduce_max_abs_sum(smi_ctx* ctx, const void* vector_field, double* out);
+int smi_reduce_max(smi_ctx* ctx, const void* field, int ncomp, double* out);
+int smi_reduce_sum_sq(smi_ctx* ctx, const void* field, int ncomp, double* out);
+
+/* ---- unbounded Poisson solver ---------------------------------------------------
+ * UnboundedPoissonSolverMPI3D (poisson_solver_3d/UnboundedPoissonSolverMPI3D.py:22-187),
+ * FFTMPI3D (fft_mpi_3d.py:5-48) and MPIDomainDoublingCommunicator3D (:190-382).
+ * dx: the real_t grid spacing; x_range: the user's x extent (the Green's function uses
+ * 2 * x_range, :102-106); global_n*: GLOBAL interior sizes. */
+int smi_poisson_create(smi_poisson** out, smi_ctx* ctx, int global_nz, int global_ny, int global_nx,
+                       double dx, double x_range, int backend);
+int smi_poisson_destroy(smi_poisson* p);
+int smi_poisson_solve(smi_poisson* p, void* solution, const void* rhs);
+int smi_poisson_vector_solve(smi_poisson* p, void* solution, const void* rhs);
+/* debug / test: download the compact Green's-function spectrum */
+size_t smi_poisson_greens_size(smi_poisson* p);
+int smi_poisson_greens_download(smi_poisson* p, void* host);
+
+/* ---- immersed boundary ------------------------------------------------------------
+ * EulerianLagrangianGridCommunicatorMPI3D.py:116-589 and VirtualBoundaryForcingMPI.py:278-459.
+ * Lagrangian arrays are DEVICE (3, M) float64; index is (3, M) int64 ordered x, y, z;
+ * support is (3,4,4,4,M) float64, weights (4,4,4,M) float64.  substart: global index of
+ * this slab's first interior cell in x, y, z order; coord_shift: eul_grid_coord_shift. */
+int smi_ib_support(smi_ctx* ctx, void* support, void* nearest_index, const void* lag_positions,
+                   int64_t m, double dx, double coord_shift, const int64_t* substart_xyz);
+int smi_ib_weights(smi_ctx* ctx, void* weights, void* support, int64_t m, double dx, int kernel_type);
+int smi_ib_interpolate(smi_ctx* ctx, void* lag_field, const void* eul_field, const void* weights,
+                       const void* nearest_index, int64_t m, int ncomp, double dx);
+int smi_ib_spread(smi_ctx* ctx, void* eul_field, const void* lag_field, const void* weights,
+                  const void* nearest_index, int64_t m, int ncomp);
+/* MPIGhostSumCommunicator3D.ghost_sum (EulerianLagrangianGridCommunicatorMPI3D.py:677-792) */
+int smi_ghost_sum(smi_ctx* ctx, void* field, int ncomp);
+/* MPIGhostSumCommunicator3D.clear_ghost_cells (:786-792) */
+int smi_clear_ghost_cells(smi_ctx* ctx, void* field, int ncomp);
+/* Fused steps 1-5 of compute_interaction_force_on_lag_grid (VirtualBoundaryForcingMPI.py:360-397):
+ * index + weights + E->L velocity + mismatch + penalty force, no support/weights arrays. */
+int smi_ib_forcing_fused(smi_ctx* ctx, void* lag_forcing, void* lag_velocity_mismatch,
+                         void* lag_flow_velocity, const void* lag_position_mismatch,
+                         const void* lag_positions, const void* lag_velocities,
+                         const void* eul_velocity, int64_t m, double dx, double coord_shift,
+                         const int64_t* substart_xyz, double stiffness, double damping,
+                         int kernel_type);
+/* Fused L->E spread that recomputes the weights from positions (step 2 of :423-429). */
+int smi_ib_spread_fused(smi_ctx* ctx, void* eul_forcing, const void* lag_forcing,
+                        const void* lag_positions, int64_t m, double dx, double coord_shift,
+                        const int64_t* substart_xyz, int kernel_type);
+/* update_lag_grid_position_mismatch_field_via_euler_forward (:297-310) */
+int smi_ib_mismatch_step(smi_ctx* ctx, void* position_mismatch, const void* velocity_mismatch,
+                         int64_t n, double dt);
+
+/* ---- fused flow step ---------------------------------------------------------------
+ * One navier_stokes / navier_stokes_with_forcing step of UnboundedFlowSimulator3D
+ * (flow_simulators_mpi_3d.py:395-424) with fused kernels.  forcing may be NULL
+ * (flow_type "navier_stokes").  free_stream: 3 doubles or NULL.  filter_order 0 = off. */
+int smi_flow_step_ns3d(smi_ctx* ctx, smi_poisson* p, void* vorticity, void* velocity,
+                       void* stream_func, void* buffer_vector, void* buffer_scalar, void* forcing,
+                       double dt, double nu, double dx, int penalty_width, const double* fac_lo,
+                       const double* fac_hi, const double* free_stream, int filter_order,
+                       int filter_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOPHTMI_H */

@@ -1,0 +1,193 @@
+// Inter-GPU plumbing of libsophtmi: RCCL communicator over the z-slab ranks, halo
+// exchange, ghost sum.  A z-slab's ghost planes are whole padded planes, contiguous in
+// memory, so they travel as they lie with ncclSend / ncclRecv: no pack or unpack pass.
+#include "smi_common.h"
+
+extern "C" int smi_comm_unique_id(void* out128) {
+  SMI_REQUIRE(out128, "smi_comm_unique_id: null output");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  SMI_CHECK_NCCL(ncclGetUniqueId(&id));
+  memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int smi_comm_init(smi_ctx* c, const void* unique_id128) {
+  SMI_REQUIRE(c && unique_id128, "smi_comm_init: null argument");
+  SMI_REQUIRE(!c->comm_ready, "smi_comm_init: communicator already initialised");
+  SMI_CHECK_HIP(hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, unique_id128, sizeof(id));
+  SMI_CHECK_NCCL(ncclCommInitRank(&c->comm, c->nranks, id, c->rank));
+  c->comm_ready = true;
+  return 0;
+}
+
+extern "C" int smi_set_exchange_callback(smi_ctx* c, smi_exchange_cb cb, void* user) {
+  SMI_REQUIRE(c, "smi_set_exchange_callback: null context");
+  c->exchange_cb = cb;
+  c->exchange_user = user;
+  return 0;
+}
+
+extern "C" int smi_allreduce_f64(smi_ctx* c, double* host_inout, int n, int op) {
+  SMI_REQUIRE(c && host_inout && n >= 1 && n <= 8, "smi_allreduce_f64: bad argument (n must be in [1, 8])");
+  SMI_REQUIRE(op >= 0 && op <= 2, "smi_allreduce_f64: bad op %d", op);
+  if (c->nranks == 1) return 0;
+  SMI_REQUIRE(c->comm_ready, "smi_allreduce_f64 needs smi_comm_init");
+  ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax);
+  SMI_CHECK_HIP(hipMemcpyAsync(c->fac_dev, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  SMI_CHECK_NCCL(ncclAllReduce(c->fac_dev, c->fac_dev, n, ncclDouble, rop, c->comm, c->stream));
+  SMI_CHECK_HIP(hipMemcpyAsync(c->red_host, c->fac_dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; ++i) host_inout[i] = c->red_host[i];
+  return 0;
+}
+
+static inline ncclDataType_t nccl_type(const smi_ctx* c) { return c->dtype == SMI_F32 ? ncclFloat : ncclDouble; }
+
+// MPIGhostCommunicator3D z faces: my first / last g interior planes -> the neighbour's
+// high / low ghost planes.
+int smi_halo_exchange_impl(smi_ctx* c, void* field, int ncomp) {
+  if (c->nranks == 1) return 0;
+  if (c->exchange_cb) {
+    int rc = c->exchange_cb(c->exchange_user, field, ncomp, 0);
+    SMI_REQUIRE(rc == 0, "halo exchange callback failed (%d)", rc);
+    return 0;
+  }
+  SMI_REQUIRE(c->comm_ready, "halo exchange across ranks needs smi_comm_init or an exchange callback");
+  const size_t es = smi_elem_size(c);
+  const size_t n = (size_t)c->g * c->plane;  // elements per face per component
+  char* base = (char*)field;
+  SMI_CHECK_NCCL(ncclGroupStart());
+  for (int k = 0; k < ncomp; ++k) {
+    char* f = base + (size_t)k * c->vol * es;
+    if (c->rank > 0) {
+      SMI_CHECK_NCCL(ncclSend(f + (size_t)c->g * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+      SMI_CHECK_NCCL(ncclRecv(f, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+    }
+    if (c->rank < c->nranks - 1) {
+      SMI_CHECK_NCCL(ncclSend(f + (size_t)(c->pz - 2 * c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
+                              c->stream));
+      SMI_CHECK_NCCL(ncclRecv(f + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
+                              c->stream));
+    }
+  }
+  SMI_CHECK_NCCL(ncclGroupEnd());
+  return 0;
+}
+
+extern "C" int smi_halo_exchange(smi_ctx* c, void* field, int ncomp) {
+  SMI_REQUIRE(c && field && ncomp >= 1, "smi_halo_exchange: bad argument");
+  return smi_halo_exchange_impl(c, field, ncomp);
+}
+
+extern "C" int smi_planes_d2h(smi_ctx* c, const void* field, int ncomp, int z0, int nplanes, void* host) {
+  SMI_REQUIRE(c && field && host && ncomp >= 1, "smi_planes_d2h: bad argument");
+  SMI_REQUIRE(z0 >= 0 && nplanes >= 1 && z0 + nplanes <= c->pz, "smi_planes_d2h: plane range out of bounds");
+  const size_t es = smi_elem_size(c), bytes = (size_t)nplanes * c->plane * es;
+  for (int k = 0; k < ncomp; ++k)
+    SMI_CHECK_HIP(hipMemcpyAsync((char*)host + k * bytes,
+                                 (const char*)field + ((size_t)k * c->vol + (size_t)z0 * c->plane) * es, bytes,
+                                 hipMemcpyDeviceToHost, c->stream));
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_add(T* __restrict__ dst, const T* __restrict__ src, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] += src[i];
+}
+
+extern "C" int smi_planes_h2d(smi_ctx* c, void* field, int ncomp, int z0, int nplanes, const void* host,
+                              int accumulate) {
+  SMI_REQUIRE(c && field && host && ncomp >= 1, "smi_planes_h2d: bad argument");
+  SMI_REQUIRE(z0 >= 0 && nplanes >= 1 && z0 + nplanes <= c->pz, "smi_planes_h2d: plane range out of bounds");
+  const size_t es = smi_elem_size(c), n = (size_t)nplanes * c->plane, bytes = n * es;
+  for (int k = 0; k < ncomp; ++k) {
+    char* dst = (char*)field + ((size_t)k * c->vol + (size_t)z0 * c->plane) * es;
+    if (!accumulate) {
+      SMI_CHECK_HIP(hipMemcpyAsync(dst, (const char*)host + k * bytes, bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+      SMI_REQUIRE(c->halo_recv[0] && bytes <= c->halo_cap, "smi_planes_h2d: staging buffer too small");
+      SMI_CHECK_HIP(hipMemcpyAsync(c->halo_recv[0], (const char*)host + k * bytes, bytes, hipMemcpyHostToDevice,
+                                   c->stream));
+      int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+      SMI_DISPATCH(c, { k_add<T><<<blocks, 256, 0, c->stream>>>((T*)dst, (const T*)c->halo_recv[0], n); });
+      SMI_LAUNCH_CHECK();
+    }
+  }
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// zero the g ghost layers on all six sides (MPIGhostSumCommunicator3D.clear_ghost_cells)
+template <typename T>
+__global__ void __launch_bounds__(256) k_clear_ghosts(T* __restrict__ f, int pz, int py, int px, int g,
+                                                      long long plane, long long vol, int ncomp) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= vol * ncomp) return;
+  long long r = i % vol;
+  int z = (int)(r / plane);
+  long long rr = r - (long long)z * plane;
+  int y = (int)(rr / px), x = (int)(rr - (long long)y * px);
+  if (x < g || x >= px - g || y < g || y >= py - g || z < g || z >= pz - g) f[i] = T(0);
+}
+
+extern "C" int smi_clear_ghost_cells(smi_ctx* c, void* field, int ncomp) {
+  SMI_REQUIRE(c && field && ncomp >= 1, "smi_clear_ghost_cells: bad argument");
+  long long n = (long long)c->vol * ncomp;
+  SMI_DISPATCH(c, {
+    k_clear_ghosts<T><<<(int)((n + 255) / 256), 256, 0, c->stream>>>((T*)field, c->pz, c->py, c->px, c->g,
+                                                                    (long long)c->plane, (long long)c->vol, ncomp);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// MPIGhostSumCommunicator3D.ghost_sum for z-slabs: my high ghost planes are added to the
+// next rank's first interior planes, my low ghost planes to the previous rank's last
+// interior planes (y and x neighbours are PROC_NULL), then all ghosts are zeroed.
+extern "C" int smi_ghost_sum(smi_ctx* c, void* field, int ncomp) {
+  SMI_REQUIRE(c && field && ncomp >= 1 && ncomp <= 3, "smi_ghost_sum: bad argument");
+  if (c->nranks > 1 && c->exchange_cb) {
+    int rc = c->exchange_cb(c->exchange_user, field, ncomp, 1);
+    SMI_REQUIRE(rc == 0, "ghost sum callback failed (%d)", rc);
+  } else if (c->nranks > 1) {
+    SMI_REQUIRE(c->comm_ready, "smi_ghost_sum across ranks needs smi_comm_init or an exchange callback");
+    const size_t es = smi_elem_size(c);
+    const size_t n = (size_t)c->g * c->plane;
+    SMI_REQUIRE((size_t)ncomp * n * es <= c->halo_cap, "smi_ghost_sum: staging buffer too small");
+    char* base = (char*)field;
+    SMI_CHECK_NCCL(ncclGroupStart());
+    for (int k = 0; k < ncomp; ++k) {
+      char* f = base + (size_t)k * c->vol * es;
+      if (c->rank > 0) {
+        SMI_CHECK_NCCL(ncclSend(f, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv((char*)c->halo_recv[0] + k * n * es, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+      }
+      if (c->rank < c->nranks - 1) {
+        SMI_CHECK_NCCL(ncclSend(f + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
+                                c->stream));
+        SMI_CHECK_NCCL(ncclRecv((char*)c->halo_recv[1] + k * n * es, n, nccl_type(c), c->rank + 1, c->comm, c->stream));
+      }
+    }
+    SMI_CHECK_NCCL(ncclGroupEnd());
+    int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    for (int k = 0; k < ncomp; ++k) {
+      char* f = base + (size_t)k * c->vol * es;
+      SMI_DISPATCH(c, {
+        if (c->rank > 0)
+          k_add<T><<<blocks, 256, 0, c->stream>>>((T*)(f + (size_t)c->g * c->plane * es),
+                                                 (const T*)((char*)c->halo_recv[0] + k * n * es), n);
+        if (c->rank < c->nranks - 1)
+          k_add<T><<<blocks, 256, 0, c->stream>>>((T*)(f + (size_t)(c->pz - 2 * c->g) * c->plane * es),
+                                                 (const T*)((char*)c->halo_recv[1] + k * n * es), n);
+      });
+      SMI_LAUNCH_CHECK();
+    }
+  }
+  return smi_clear_ghost_cells(c, field, ncomp);
+}

@@ -1,0 +1,110 @@
+// Internal definitions shared by the libsophtmi translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "sophtmi.h"
+
+struct SmiProf;
+
+struct smi_ctx {
+  int device;
+  int dtype;           // SMI_F32 / SMI_F64
+  int nz, ny, nx, g;   // local interior sizes, ghost layers
+  int pz, py, px;      // padded sizes
+  size_t plane;        // py * px
+  size_t vol;          // pz * py * px
+  int rank, nranks;
+  int phys_zlo, phys_zhi;  // is the low / high z face a physical boundary
+  hipStream_t stream;
+  hipStream_t comm_stream;
+  hipEvent_t ev_a, ev_b;
+  void* red_partials;  // device, double[kRedBlocks]
+  double* red_host;    // pinned
+  ncclComm_t comm;
+  bool comm_ready;
+  void* halo_recv[2];  // device staging: [0] from previous rank, [1] from next rank
+  size_t halo_cap;     // bytes per staging buffer
+  void* fac_dev;       // small device scratch (allreduce staging)
+  smi_exchange_cb exchange_cb;
+  SmiProf* prof;
+  void* exchange_user;
+};
+
+constexpr int kRedBlocks = 2048;
+
+void smi_set_error(const char* fmt, ...);
+
+#define SMI_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      smi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return 1;                                                                          \
+    }                                                                                    \
+  } while (0)
+
+#define SMI_CHECK_NCCL(expr)                                                              \
+  do {                                                                                    \
+    ncclResult_t _e = (expr);                                                             \
+    if (_e != ncclSuccess) {                                                              \
+      smi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_e)); \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+#define SMI_REQUIRE(cond, ...)    \
+  do {                            \
+    if (!(cond)) {                \
+      smi_set_error(__VA_ARGS__); \
+      return 1;                   \
+    }                             \
+  } while (0)
+
+#define SMI_CHECK(expr)      \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != 0) return _r;  \
+  } while (0)
+
+#define SMI_LAUNCH_CHECK() SMI_CHECK_HIP(hipGetLastError())
+
+// Run `body` with T bound to the context's real type.
+#define SMI_DISPATCH(ctx, ...)      \
+  do {                              \
+    if ((ctx)->dtype == SMI_F32) {  \
+      using T = float;              \
+      __VA_ARGS__                   \
+    } else {                        \
+      using T = double;             \
+      __VA_ARGS__                   \
+    }                               \
+  } while (0)
+
+static inline size_t smi_elem_size(const smi_ctx* c) { return c->dtype == SMI_F32 ? 4 : 8; }
+
+template <typename T>
+struct alignas(sizeof(T) * 4) Vec4 {
+  T v[4];
+};
+
+// 16-byte (f32) / 32-byte (f64) vector access of four consecutive reals; p must be
+// aligned to 4 elements.
+template <typename T>
+__device__ __forceinline__ Vec4<T> load4(const T* p) {
+  return *reinterpret_cast<const Vec4<T>*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const Vec4<T>& v) {
+  *reinterpret_cast<Vec4<T>*>(p) = v;
+}
+
+// internal cross-TU helpers
+int smi_halo_exchange_impl(smi_ctx* ctx, void* field, int ncomp);
+// true when this context has neighbours to exchange with
+static inline bool smi_multi_rank(const smi_ctx* c) { return c->nranks > 1; }

@@ -1,0 +1,561 @@
+// Stencil operators of libsophtmi (gfx950): diffusion flux, curl / vorticity update,
+// divergence, boundary penalisation, Laplacian filter.
+//
+// Layout: every field is a ghosted [z][y][x] array.  A z-plane is treated as a flat
+// array of py*px reals: lane i of a workgroup owns V = 4 consecutive reals (one 16-byte
+// access for f32) at flat plane offset q, so loads and stores are fully coalesced and
+// the y+-1 neighbours are the same flat vector shifted by +-px (still 16-byte aligned
+// because px % 4 == 0 on the vector path).  Each lane marches along z over a chunk of
+// planes keeping the z-1 / z / z+1 values in registers, so every plane is fetched from
+// HBM once per chunk (+2 halo planes); the y+-1 and x+-1 re-reads hit L1/L2.
+//
+// Which cells an operator writes follows the reference MPI wrappers exactly (seven
+// overlapping boxes per call, then zeroing of the physical boundary bands):
+//   D = { z in [zlo_c, zhi_c], y and x in [g+1, p-g-2] }   for flux / curl / filter
+//   U = A + B + C                                          for the vorticity update
+// with the sets spelled out at each kernel.
+#include "smi_common.h"
+#include "smi_prof.h"
+
+namespace {
+
+struct Geo {
+  int pz, py, px, g;
+  long long plane, vol;
+  int zlo_c, zhi_c;  // inclusive z range of the zero-banded compute set D
+};
+
+Geo make_geo(const smi_ctx* c) {
+  Geo G;
+  G.pz = c->pz;
+  G.py = c->py;
+  G.px = c->px;
+  G.g = c->g;
+  G.plane = (long long)c->plane;
+  G.vol = (long long)c->vol;
+  // diffusion_flux_mpi_3d.py:161-192: g+1 layers are zeroed next to physical faces;
+  // at a rank boundary the first / last interior plane is computed from exchanged ghosts.
+  G.zlo_c = c->g + (c->phys_zlo ? 1 : 0);
+  G.zhi_c = c->pz - c->g - 1 - (c->phys_zhi ? 1 : 0);
+  return G;
+}
+
+constexpr int kBlock = 256;
+
+struct LaunchShape {
+  dim3 grid;
+  int zchunk;
+};
+
+template <int V>
+LaunchShape plan(const smi_ctx* c, int ncomp) {
+  long long lanes = ((long long)c->plane + V - 1) / V;
+  int bx = (int)((lanes + kBlock - 1) / kBlock);
+  // aim for >= 2048 workgroups while keeping z chunks long enough to amortise the two
+  // halo planes each chunk re-reads
+  int zchunk = (int)((long long)c->pz * bx * ncomp / 2048);
+  if (zchunk < 8) zchunk = 8;
+  if (zchunk > 32) zchunk = 32;
+  if (zchunk > c->pz) zchunk = c->pz;
+  int nchunk = (c->pz + zchunk - 1) / zchunk;
+  LaunchShape s;
+  s.grid = dim3(bx, nchunk, ncomp);
+  s.zchunk = zchunk;
+  return s;
+}
+
+template <typename T, int V>
+struct Pack {
+  T v[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ld(const T* p) {
+  Pack<T, V> r;
+  if constexpr (V == 4) {
+    Vec4<T> t = load4(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = t.v[e];
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ void st(T* p, const Pack<T, V>& r) {
+  if constexpr (V == 4) {
+    Vec4<T> t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t.v[e] = r.v[e];
+    store4(p, t);
+  } else {
+    p[0] = r.v[0];
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> zero_pack() {
+  Pack<T, V> r;
+#pragma unroll
+  for (int e = 0; e < V; ++e) r.v[e] = T(0);
+  return r;
+}
+
+// flat plane offset of this lane, its row and first column; false when past the plane
+template <int V>
+__device__ __forceinline__ bool lane_pos(const Geo& G, long long& q, int& y, int& x0) {
+  q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (q >= G.plane) return false;
+  y = (int)(q / G.px);
+  x0 = (int)(q - (long long)y * G.px);
+  return true;
+}
+
+__device__ __forceinline__ bool in_core(int a, int p, int g) { return a >= g + 1 && a <= p - g - 2; }
+__device__ __forceinline__ bool on_face(int a, int p, int g) { return a == g || a == p - g - 1; }
+__device__ __forceinline__ bool in_ext(int a, int p) { return a >= 1 && a <= p - 2; }
+
+// ---------------------------------------------------------------- diffusion flux
+// flux = c * (sum of the six neighbours - 6 f) on D, 0 elsewhere.
+template <typename T, int V>
+__global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux, const T* __restrict__ f, T c,
+                                                           Geo G, int zchunk) {
+  long long q;
+  int y, x0;
+  if (!lane_pos<V>(G, q, y, x0)) return;
+  flux += (long long)blockIdx.z * G.vol + q;
+  f += (long long)blockIdx.z * G.vol + q;
+  bool core[V], any = false;
+  bool ycore = in_core(y, G.py, G.g);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    core[e] = ycore && in_core(x0 + e, G.px, G.g);
+    any |= core[e];
+  }
+  int z0 = blockIdx.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
+  const Pack<T, V> zero = zero_pack<T, V>();
+  if (!any || zs > ze) {
+    for (int z = z0; z < z1; ++z) st<T, V>(flux + z * G.plane, zero);
+    return;
+  }
+  for (int z = z0; z < zs; ++z) st<T, V>(flux + z * G.plane, zero);
+  Pack<T, V> prev = ld<T, V>(f + (zs - 1) * G.plane), cur = ld<T, V>(f + zs * G.plane);
+  for (int z = zs; z <= ze; ++z) {
+    const T* pc = f + z * G.plane;
+    Pack<T, V> nxt = ld<T, V>(pc + G.plane);
+    Pack<T, V> ym = ld<T, V>(pc - G.px), yp = ld<T, V>(pc + G.px);
+    T xm = pc[-1], xp = pc[V];
+    Pack<T, V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      T left = e == 0 ? xm : cur.v[e - 1];
+      T right = e == V - 1 ? xp : cur.v[e + 1];
+      T val = c * (right + left + yp.v[e] + ym.v[e] + nxt.v[e] + prev.v[e] - T(6) * cur.v[e]);
+      o.v[e] = core[e] ? val : T(0);
+    }
+    st<T, V>(flux + z * G.plane, o);
+    prev = cur;
+    cur = nxt;
+  }
+  for (int z = ze + 1; z < z1; ++z) st<T, V>(flux + z * G.plane, zero);
+}
+
+// ---------------------------------------------------------------- curl / vorticity update
+// MODE 0 (curl_mpi_3d.py):            out = p * curl(f) on D, 0 elsewhere.
+// MODE 1 (update_vorticity_..._3d.py): out += p * curl(f) on U = A + B + C where, with
+//   core(a) = a in [g+1, p-g-2], face(a) = a in {g, p-g-1}, ext(a) = a in [1, p-2]:
+//   A = { z in [g, pz-g-1], core(y), core(x) }      interior box and the two z boxes
+//   B = { ext(z), face(y), core(x) }                the two y boxes
+//   C = { ext(z), ext(y), face(x) }                 the two x boxes
+// (no band zeroing: update_vorticity_from_velocity_forcing_mpi_3d.py has no PROC_NULL logic).
+template <typename T, int V, int MODE>
+__global__ void __launch_bounds__(kBlock) k_curl(T* __restrict__ out, const T* __restrict__ f, T pref, Geo G,
+                                                 int zchunk) {
+  long long q;
+  int y, x0;
+  if (!lane_pos<V>(G, q, y, x0)) return;
+  const T* fx = f + q;
+  const T* fy = f + G.vol + q;
+  const T* fz = f + 2 * G.vol + q;
+  T* ox = out + q;
+  T* oy = out + G.vol + q;
+  T* oz = out + 2 * G.vol + q;
+  bool mA[V], mB[V], any = false;
+  const bool yc = in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
+    mA[e] = yc && xc;
+    mB[e] = MODE == 1 && ((yf && xc) || (ye && xf));
+    any |= mA[e] || mB[e];
+  }
+  int z0 = blockIdx.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  int zs, ze;
+  if (MODE == 0) {
+    zs = max(z0, G.zlo_c);
+    ze = min(z1 - 1, G.zhi_c);
+  } else {
+    zs = max(z0, 1);
+    ze = min(z1 - 1, G.pz - 2);
+  }
+  const Pack<T, V> zero = zero_pack<T, V>();
+  if (!any || zs > ze) {
+    if (MODE == 0)
+      for (int z = z0; z < z1; ++z) {
+        st<T, V>(ox + z * G.plane, zero);
+        st<T, V>(oy + z * G.plane, zero);
+        st<T, V>(oz + z * G.plane, zero);
+      }
+    return;
+  }
+  if (MODE == 0)
+    for (int z = z0; z < zs; ++z) {
+      st<T, V>(ox + z * G.plane, zero);
+      st<T, V>(oy + z * G.plane, zero);
+      st<T, V>(oz + z * G.plane, zero);
+    }
+  Pack<T, V> fx_prev = ld<T, V>(fx + (zs - 1) * G.plane), fx_cur = ld<T, V>(fx + zs * G.plane);
+  Pack<T, V> fy_prev = ld<T, V>(fy + (zs - 1) * G.plane), fy_cur = ld<T, V>(fy + zs * G.plane);
+  for (int z = zs; z <= ze; ++z) {
+    const long long zo = z * G.plane;
+    Pack<T, V> fx_nxt = ld<T, V>(fx + zo + G.plane), fy_nxt = ld<T, V>(fy + zo + G.plane);
+    Pack<T, V> fx_ym = ld<T, V>(fx + zo - G.px), fx_yp = ld<T, V>(fx + zo + G.px);
+    Pack<T, V> fz_ym = ld<T, V>(fz + zo - G.px), fz_yp = ld<T, V>(fz + zo + G.px);
+    Pack<T, V> fz_c = ld<T, V>(fz + zo);
+    T fy_xm = fy[zo - 1], fy_xp = fy[zo + V];
+    T fz_xm = fz[zo - 1], fz_xp = fz[zo + V];
+    Pack<T, V> rx, ry, rz;
+    bool m[V], anym = false;
+    const bool zA = z >= G.g && z <= G.pz - G.g - 1;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      T fyL = e == 0 ? fy_xm : fy_cur.v[e - 1], fyR = e == V - 1 ? fy_xp : fy_cur.v[e + 1];
+      T fzL = e == 0 ? fz_xm : fz_c.v[e - 1], fzR = e == V - 1 ? fz_xp : fz_c.v[e + 1];
+      rx.v[e] = pref * (fz_yp.v[e] - fz_ym.v[e] - fy_nxt.v[e] + fy_prev.v[e]);
+      ry.v[e] = pref * (fx_nxt.v[e] - fx_prev.v[e] - fzR + fzL);
+      rz.v[e] = pref * (fyR - fyL - fx_yp.v[e] + fx_ym.v[e]);
+      m[e] = MODE == 0 ? mA[e] : (mB[e] || (mA[e] && zA));
+      anym |= m[e];
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        rx.v[e] = m[e] ? rx.v[e] : T(0);
+        ry.v[e] = m[e] ? ry.v[e] : T(0);
+        rz.v[e] = m[e] ? rz.v[e] : T(0);
+      }
+      st<T, V>(ox + zo, rx);
+      st<T, V>(oy + zo, ry);
+      st<T, V>(oz + zo, rz);
+    } else if (anym) {
+      Pack<T, V> wx = ld<T, V>(ox + zo), wy = ld<T, V>(oy + zo), wz = ld<T, V>(oz + zo);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        wx.v[e] = m[e] ? wx.v[e] + rx.v[e] : wx.v[e];
+        wy.v[e] = m[e] ? wy.v[e] + ry.v[e] : wy.v[e];
+        wz.v[e] = m[e] ? wz.v[e] + rz.v[e] : wz.v[e];
+      }
+      st<T, V>(ox + zo, wx);
+      st<T, V>(oy + zo, wy);
+      st<T, V>(oz + zo, wz);
+    }
+    fx_prev = fx_cur;
+    fx_cur = fx_nxt;
+    fy_prev = fy_cur;
+    fy_cur = fy_nxt;
+  }
+  if (MODE == 0)
+    for (int z = ze + 1; z < z1; ++z) {
+      st<T, V>(ox + z * G.plane, zero);
+      st<T, V>(oy + z * G.plane, zero);
+      st<T, V>(oz + z * G.plane, zero);
+    }
+}
+
+// ---------------------------------------------------------------- divergence (diagnostic)
+// div = (0.5 * inv_dx) * (dfx/dx + dfy/dy + dfz/dz central differences) on D, 0 elsewhere.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_divergence(T* __restrict__ div, const T* __restrict__ f, T half_inv_dx,
+                                                       Geo G) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.vol) return;
+  int z = (int)(i / G.plane);
+  long long r = i - (long long)z * G.plane;
+  int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
+  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core(y, G.py, G.g) && in_core(x, G.px, G.g);
+  T v = T(0);
+  if (ok) {
+    const T* fx = f + i;
+    const T* fy = f + G.vol + i;
+    const T* fz = f + 2 * G.vol + i;
+    v = half_inv_dx * (fx[1] - fx[-1] + fy[G.px] - fy[-G.px] + fz[G.plane] - fz[-G.plane]);
+  }
+  div[i] = v;
+}
+
+// ---------------------------------------------------------------- Laplacian filter pass
+// flux = 0.25 * (-f(+1) - f(-1) + 2 f) along AXIS (0 = x, 1 = y, 2 = z) on D, 0 elsewhere
+// (laplacian_filter_mpi_3d.py:62-99 followed by the band clearing of :110-143).
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(kBlock) k_filter_pass(T* __restrict__ flux, const T* __restrict__ f, Geo G) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.vol) return;
+  int z = (int)(i / G.plane);
+  long long r = i - (long long)z * G.plane;
+  int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
+  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core(y, G.py, G.g) && in_core(x, G.px, G.g);
+  T v = T(0);
+  if (ok) {
+    const long long d = AXIS == 0 ? 1 : (AXIS == 1 ? (long long)G.px : G.plane);
+    v = T(0.25) * (-f[i + d] - f[i - d] + T(2) * f[i]);
+  }
+  flux[i] = v;
+}
+
+// zero the outer (g + width) layers next to physical faces (zero_bands of the wrappers)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_zero_bands(T* __restrict__ f, Geo G, int w, int zlo, int zhi) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.vol) return;
+  int z = (int)(i / G.plane);
+  long long r = i - (long long)z * G.plane;
+  int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
+  bool band = x < w || x >= G.px - w || y < w || y >= G.py - w || (zlo && z < w) || (zhi && z >= G.pz - w);
+  if (band) f[i] = T(0);
+}
+
+// ---------------------------------------------------------------- penalise boundary
+struct PenFac {
+  double lo[3][16];  // [axis x,y,z][band index from the outermost cell inward]
+  double hi[3][16];  // [axis][band index from the first cell of the high band outward]
+};
+
+// AXIS 0: one lane per (comp, z, y) line; AXIS 1: per (comp, z, x); AXIS 2: per (comp, y, x).
+// Copies layer w-1 (resp. p-w) across the band, then multiplies by the sine factor
+// (penalise_field_boundary_mpi_3d.py:196-242).
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(kBlock) k_penalise(T* __restrict__ f, Geo G, int ncomp, int w, PenFac fac,
+                                                     int do_lo, int do_hi) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long lines = AXIS == 0 ? (long long)G.pz * G.py : (AXIS == 1 ? (long long)G.pz * G.px : G.plane);
+  if (i >= lines * ncomp) return;
+  int comp = (int)(i / lines);
+  long long l = i - comp * lines;
+  T* base;
+  long long stride;
+  int p;
+  if (AXIS == 0) {
+    base = f + comp * G.vol + l * G.px;
+    stride = 1;
+    p = G.px;
+  } else if (AXIS == 1) {
+    long long z = l / G.px, x = l - z * G.px;
+    base = f + comp * G.vol + z * G.plane + x;
+    stride = G.px;
+    p = G.py;
+  } else {
+    base = f + comp * G.vol + l;
+    stride = G.plane;
+    p = G.pz;
+  }
+  if (do_lo) {
+    T src = base[(w - 1) * stride];
+    for (int k = 0; k < w; ++k) base[k * stride] = src * (T)fac.lo[AXIS][k];
+  }
+  if (do_hi) {
+    T src = base[(p - w) * stride];
+    for (int k = 0; k < w; ++k) base[(p - w + k) * stride] = src * (T)fac.hi[AXIS][k];
+  }
+}
+
+template <typename T>
+bool vec_ok(const smi_ctx* c, const void* a, const void* b) {
+  return c->px % 4 == 0 && ((uintptr_t)a % (4 * sizeof(T))) == 0 && ((uintptr_t)b % (4 * sizeof(T))) == 0 &&
+         (c->vol % 4) == 0;
+}
+
+int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int smi_diffusion_flux(smi_ctx* c, void* flux, const void* field, double prefactor, int ncomp) {
+  SMI_REQUIRE(c && flux && field && ncomp >= 1, "smi_diffusion_flux: bad argument");
+  SMI_REQUIRE(flux != field, "smi_diffusion_flux: flux and field must not alias");
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, (void*)field, ncomp));
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, PROF_DIFFUSION_FLUX, 2.0 * ncomp * smi_S(c));
+  SMI_DISPATCH(c, {
+    if (vec_ok<T>(c, flux, field)) {
+      LaunchShape s = plan<4>(c, ncomp);
+      k_diffusion_flux<T, 4><<<s.grid, kBlock, 0, c->stream>>>((T*)flux, (const T*)field, (T)prefactor, G, s.zchunk);
+    } else {
+      LaunchShape s = plan<1>(c, ncomp);
+      k_diffusion_flux<T, 1><<<s.grid, kBlock, 0, c->stream>>>((T*)flux, (const T*)field, (T)prefactor, G, s.zchunk);
+    }
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi_diffusion_timestep(smi_ctx* c, void* field, void* flux, double nu_dt_by_dx2, int ncomp) {
+  SMI_REQUIRE(c && flux && field && ncomp >= 1, "smi_diffusion_timestep: bad argument");
+  for (int k = 0; k < ncomp; ++k) {
+    void* fk = (char*)field + (size_t)k * c->vol * smi_elem_size(c);
+    SMI_CHECK(smi_diffusion_flux(c, flux, fk, nu_dt_by_dx2, 1));
+    SMI_CHECK(smi_elementwise_sum(c, fk, fk, flux, 1));
+  }
+  return 0;
+}
+
+template <int MODE>
+static int run_curl(smi_ctx* c, void* out, void* f, double prefactor) {
+  SMI_REQUIRE(out != f, "curl operators: output and input must not alias");
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, MODE == 1 ? PROF_CURL_UPDATE : PROF_CURL, (MODE == 1 ? 9.0 : 6.0) * smi_S(c));
+  SMI_DISPATCH(c, {
+    if (vec_ok<T>(c, out, f)) {
+      LaunchShape s = plan<4>(c, 1);
+      k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
+    } else {
+      LaunchShape s = plan<1>(c, 1);
+      k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
+    }
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vorticity, void* forcing,
+                                                          double prefactor) {
+  SMI_REQUIRE(c && vorticity && forcing, "smi_update_vorticity_from_velocity_forcing: bad argument");
+  return run_curl<1>(c, vorticity, forcing, prefactor);
+}
+
+extern "C" int smi_curl(smi_ctx* c, void* curl, void* field, double prefactor) {
+  SMI_REQUIRE(c && curl && field, "smi_curl: bad argument");
+  return run_curl<0>(c, curl, field, prefactor);
+}
+
+extern "C" int smi_divergence(smi_ctx* c, void* divergence, void* field, double inv_dx) {
+  SMI_REQUIRE(c && divergence && field, "smi_divergence: bad argument");
+  SMI_REQUIRE(divergence != field, "smi_divergence: output and input must not alias");
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, field, 3));
+  Geo G = make_geo(c);
+  SMI_DISPATCH(c, {
+    T h = (T)0.5 * (T)inv_dx;
+    k_divergence<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>((T*)divergence, (const T*)field, h, G);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi_penalise_boundary(smi_ctx* c, void* field, int ncomp, int width, const double* fac_lo,
+                                     const double* fac_hi) {
+  SMI_REQUIRE(c && field && ncomp >= 1, "smi_penalise_boundary: bad argument");
+  SMI_REQUIRE(width >= 0, "invalid zone width");
+  if (width == 0) return 0;
+  int w = c->g + width;
+  SMI_REQUIRE(w <= 16, "smi_penalise_boundary: ghost + width = %d exceeds 16", w);
+  SMI_REQUIRE(fac_lo && fac_hi, "smi_penalise_boundary: null factor tables");
+  SMI_REQUIRE(2 * w <= c->px && 2 * w <= c->py && 2 * w <= c->pz,
+              "smi_penalise_boundary: penalty bands overlap on this grid");
+  PenFac fac;
+  for (int a = 0; a < 3; ++a)
+    for (int k = 0; k < w; ++k) {
+      fac.lo[a][k] = fac_lo[a * w + k];
+      fac.hi[a][k] = fac_hi[a * w + k];
+    }
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, PROF_PENALISE, 0.0);
+  SMI_DISPATCH(c, {
+    k_penalise<T, 0><<<blocks_for((long long)G.pz * G.py * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
+                                                                                         fac, 1, 1);
+    k_penalise<T, 1><<<blocks_for((long long)G.pz * G.px * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
+                                                                                         fac, 1, 1);
+    if (c->phys_zlo || c->phys_zhi)
+      k_penalise<T, 2><<<blocks_for(G.plane * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w, fac,
+                                                                             c->phys_zlo, c->phys_zhi);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int filter_pass(smi_ctx* c, const Geo& G, int axis, T* flux, T* src) {
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, src, 1));
+  int b = blocks_for(G.vol);
+  if (axis == 0)
+    k_filter_pass<T, 0><<<b, kBlock, 0, c->stream>>>(flux, src, G);
+  else if (axis == 1)
+    k_filter_pass<T, 1><<<b, kBlock, 0, c->stream>>>(flux, src, G);
+  else
+    k_filter_pass<T, 2><<<b, kBlock, 0, c->stream>>>(flux, src, G);
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* filter_flux_buffer,
+                                    void* field_buffer, int order, int filter_type) {
+  SMI_REQUIRE(c && field && filter_flux_buffer && field_buffer && ncomp >= 1, "smi_laplacian_filter: bad argument");
+  SMI_REQUIRE(order >= 0, "Invalid filter order");
+  SMI_REQUIRE(filter_type == SMI_FILTER_MULTIPLICATIVE || filter_type == SMI_FILTER_CONVOLUTION,
+              "Invalid filter type");
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, PROF_FILTER, 2.0 * ncomp * smi_S(c));
+  SMI_DISPATCH(c, {
+    T* flux = (T*)filter_flux_buffer;
+    T* buf = (T*)field_buffer;
+    for (int k = 0; k < ncomp; ++k) {
+      T* f = (T*)field + (size_t)k * c->vol;
+      // The reference copies the flux back into field_buffer after every directional pass;
+      // here the two scratch fields alternate roles instead.  Each pass writes every cell
+      // (0 outside D), so the result is the same and two field copies per pass are saved.
+      if (filter_type == SMI_FILTER_MULTIPLICATIVE) {
+        if (order == 0) {
+          // degenerate: field -= (stale flux buffer with its physical bands cleared)
+          k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + 1, c->phys_zlo, c->phys_zhi);
+          SMI_LAUNCH_CHECK();
+          SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
+          continue;
+        }
+        T* src = f;
+        T* dst = flux;
+        for (int it = 0; it < order; ++it)
+          for (int axis = 0; axis < 3; ++axis) {
+            SMI_CHECK(filter_pass<T>(c, G, axis, dst, src));
+            src = dst;
+            dst = (dst == flux) ? buf : flux;
+          }
+        SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, src, -1.0, 1));
+      } else {
+        for (int axis = 0; axis < 3; ++axis) {
+          if (order == 0) {
+            k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + 1, c->phys_zlo, c->phys_zhi);
+            SMI_LAUNCH_CHECK();
+            SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
+            continue;
+          }
+          T* src = f;
+          T* dst = flux;
+          for (int it = 0; it < order; ++it) {
+            SMI_CHECK(filter_pass<T>(c, G, axis, dst, src));
+            src = dst;
+            dst = (dst == flux) ? buf : flux;
+          }
+          SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, src, -1.0, 1));
+        }
+      }
+    }
+  });
+  return 0;
+}
+
+extern "C" int smi_advection_timestep_eno3(smi_ctx* c, void* field, void* flux, void* velocity, double dt_by_dx,
+                                           int ncomp) {
+  (void)c; (void)field; (void)flux; (void)velocity; (void)dt_by_dx; (void)ncomp;
+  smi_set_error("smi_advection_timestep_eno3: the ENO3 flux body lives in the un-vendored sopht package and is "
+                "not implemented on the GPU yet (3D Navier-Stokes does not use it)");
+  return 2;
+}

@@ -1,0 +1,40 @@
+// One Navier-Stokes flow step sequenced inside the library (flow_simulators_mpi_3d.py:395-424),
+// so that the host pays one call per step instead of one per operator.
+#include "smi_common.h"
+
+extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
+                                  void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
+                                  double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
+                                  const double* free_stream, int filter_order, int filter_type) {
+  SMI_REQUIRE(c && p && vorticity && velocity && stream_func && buffer_vector && buffer_scalar,
+              "smi_flow_step_ns3d: null argument");
+  // the prefactors are rounded to the real type exactly as the reference does with real_t(...)
+  double pref_curl, pref_diff, pref_vel;
+  if (c->dtype == SMI_F32) {
+    pref_curl = (double)(float)(dt / (2 * dx));
+    pref_diff = (double)(float)(nu * dt / dx / dx);
+    pref_vel = (double)(float)(0.5 / dx);
+  } else {
+    pref_curl = dt / (2 * dx);
+    pref_diff = nu * dt / dx / dx;
+    pref_vel = 0.5 / dx;
+  }
+  if (forcing) SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, forcing, pref_curl));
+  SMI_CHECK(smi_cross_product(c, buffer_vector, velocity, vorticity));
+  SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, buffer_vector, pref_curl));
+  SMI_CHECK(smi_diffusion_timestep(c, vorticity, buffer_scalar, pref_diff, 3));
+  if (filter_order > 0) {
+    size_t stride = c->vol * smi_elem_size(c);
+    SMI_CHECK(smi_laplacian_filter(c, vorticity, 3, buffer_vector, (char*)buffer_vector + stride, filter_order,
+                                   filter_type));
+  }
+  SMI_CHECK(smi_penalise_boundary(c, vorticity, 3, penalty_width, fac_lo, fac_hi));
+  SMI_CHECK(smi_poisson_vector_solve(p, stream_func, vorticity));
+  SMI_CHECK(smi_curl(c, velocity, stream_func, pref_vel));
+  if (free_stream) SMI_CHECK(smi_add_fixed_val(c, velocity, velocity, 3, free_stream));
+  if (forcing) {
+    double z3[3] = {0, 0, 0};
+    SMI_CHECK(smi_set_fixed_val(c, forcing, 3, z3));
+  }
+  return 0;
+}

@@ -1,0 +1,261 @@
+"""Device context and device-resident fields.
+
+The reference's fields are caller-owned numpy arrays (with ghost cells) that operators
+mutate in place.  Here they live in HBM; ``DeviceField`` keeps the numpy *calling
+convention* (``field[...] = values``, ``field[idx]``, ``np.asarray(field)``,
+``field[0]`` for a vector component, ``.view()``) with an explicit cost model: every
+host access is a PCIe copy, every operator call is device-only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import call, lib
+
+
+def _dtype_code(real_t):
+    dt = np.dtype(real_t)
+    if dt == np.float32:
+        return _lib.SMI_F32
+    if dt == np.float64:
+        return _lib.SMI_F64
+    raise ValueError(f"unsupported real type {real_t}")
+
+
+def local_device():
+    """GPU this process drives: LOCAL_RANK modulo the visible device count."""
+    n = C.c_int(0)
+    call("smi_device_count", C.byref(n))
+    if n.value < 1:
+        raise _lib.SophtMIError("no HIP device visible")
+    return int(os.environ.get("LOCAL_RANK", "0")) % n.value
+
+
+class DeviceContext:
+    """One GPU holding one z-slab: grid geometry + HIP stream + (optionally) RCCL comm."""
+
+    def __init__(self, local_grid_size, ghost_size, real_t, rank=0, nranks=1, device=None, world=None):
+        self.real_t = np.dtype(real_t).type
+        self.local_grid_size = tuple(int(n) for n in local_grid_size)
+        self.ghost_size = int(ghost_size)
+        self.rank, self.nranks = int(rank), int(nranks)
+        self.world = world
+        self.device = local_device() if device is None else device
+        nz, ny, nx = self.local_grid_size
+        h = C.c_void_p()
+        call("smi_ctx_create", C.byref(h), self.device, _dtype_code(real_t), nz, ny, nx, self.ghost_size,
+             self.rank, self.nranks)
+        self.handle = h
+        self.padded_shape = tuple(n + 2 * self.ghost_size for n in self.local_grid_size)
+        self.transport = "none" if nranks == 1 else None
+        self._cb = None
+
+    # -- transports ---------------------------------------------------------------
+    def init_rccl(self):
+        """RCCL communicator over the slab ranks (one process per GPU)."""
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            call("smi_comm_unique_id", buf)
+        uid = self.world.bcast_bytes(buf.raw, root=0)
+        call("smi_comm_init", self.handle, C.create_string_buffer(uid, 128))
+        self.transport = "rccl"
+
+    def init_host_staged(self):
+        """Host-staged plane transport through the world's point-to-point (ranks sharing a GPU)."""
+        g, pz = self.ghost_size, self.padded_shape[0]
+        plane = self.padded_shape[1] * self.padded_shape[2]
+        prev = self.rank - 1 if self.rank > 0 else None
+        nxt = self.rank + 1 if self.rank < self.nranks - 1 else None
+        dt = np.dtype(self.real_t)
+
+        def exchange(_user, field, ncomp, kind):
+            try:
+                n = ncomp * g * plane
+                send, recv = {}, {}
+                # kind 0 (halo): interior edge planes go out, ghost planes come in
+                # kind 1 (ghost sum): ghost planes go out, are ADDED to the neighbour's edge planes
+                src_lo, src_hi = (g, pz - 2 * g) if kind == 0 else (0, pz - g)
+                dst_lo, dst_hi = (0, pz - g) if kind == 0 else (g, pz - 2 * g)
+                if prev is not None:
+                    send[prev] = np.empty(n, dtype=dt)
+                    call("smi_planes_d2h", self.handle, field, ncomp, src_lo, g, send[prev].ctypes.data)
+                    recv[prev] = np.empty(n, dtype=dt)
+                if nxt is not None:
+                    send[nxt] = np.empty(n, dtype=dt)
+                    call("smi_planes_d2h", self.handle, field, ncomp, src_hi, g, send[nxt].ctypes.data)
+                    recv[nxt] = np.empty(n, dtype=dt)
+                self.world.sendrecv(send, recv)
+                if prev is not None:
+                    call("smi_planes_h2d", self.handle, field, ncomp, dst_lo, g, recv[prev].ctypes.data, kind)
+                if nxt is not None:
+                    call("smi_planes_h2d", self.handle, field, ncomp, dst_hi, g, recv[nxt].ctypes.data, kind)
+                return 0
+            except Exception as exc:  # never let an exception cross the C boundary
+                import traceback
+
+                traceback.print_exc()
+                self._cb_error = exc
+                return 1
+
+        self._cb = _lib.EXCHANGE_CB(exchange)
+        call("smi_set_exchange_callback", self.handle, self._cb, None)
+        self.transport = "host"
+
+    def allreduce(self, value, op):
+        if self.nranks == 1:
+            return value
+        if self.transport == "rccl":
+            buf = _lib.darray([value])
+            call("smi_allreduce_f64", self.handle, buf, 1, {"sum": 0, "min": 1, "max": 2}[op])
+            return buf[0]
+        return self.world.allreduce(value, op)
+
+    # -- memory -------------------------------------------------------------------
+    def sync(self):
+        call("smi_sync", self.handle)
+
+    def zeros(self, shape, dtype=None):
+        return DeviceField(self, shape, self.real_t if dtype is None else dtype)
+
+    def field(self, ncomp=None):
+        """Ghosted scalar (ncomp None) or vector field of this slab, zero-initialised."""
+        shape = self.padded_shape if ncomp is None else (ncomp,) + self.padded_shape
+        return self.zeros(shape)
+
+    def from_numpy(self, arr, dtype=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        f = DeviceField(self, arr.shape, arr.dtype, zero=False)
+        f.set(arr)
+        return f
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib.smi_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _Allocation:
+    """Owns one device allocation; views keep it alive."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        p = C.c_void_p()
+        call("smi_malloc", ctx.handle, nbytes, C.byref(p))
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                lib.smi_free(self.ctx.handle, C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+class DeviceField:
+    """C-contiguous array in HBM with numpy-flavoured host access."""
+
+    __array_priority__ = 100
+
+    def __init__(self, ctx, shape, dtype, zero=True, _alloc=None, _offset=0):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self.ndim = len(self.shape)
+        if _alloc is None:
+            self._alloc = _Allocation(ctx, max(self.nbytes, 16))
+            self._offset = 0
+            if zero and self.nbytes:
+                call("smi_memset_zero", ctx.handle, self.ptr, self.nbytes)
+        else:
+            self._alloc = _alloc
+            self._offset = _offset
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self._alloc.ptr + self._offset)
+
+    # -- host access --------------------------------------------------------------
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            call("smi_memcpy_d2h", self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def set(self, values):
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=self.dtype), self.shape))
+        if self.nbytes:
+            call("smi_memcpy_h2d", self.ctx.handle, self.ptr, arr.ctypes.data, self.nbytes)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype)
+
+    def view(self):
+        return DeviceField(self.ctx, self.shape, self.dtype, _alloc=self._alloc, _offset=self._offset)
+
+    def _is_full(self, idx):
+        if idx is Ellipsis:
+            return True
+        if isinstance(idx, slice):
+            return idx == slice(None)
+        if isinstance(idx, tuple):
+            return all(i is Ellipsis or (isinstance(i, slice) and i == slice(None)) for i in idx)
+        return False
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)) and self.ndim >= 2:
+            # leading-axis element (a vector component): a device view, no copy
+            k = int(idx) % self.shape[0]
+            sub = self.shape[1:]
+            stride = int(np.prod(sub)) * self.dtype.itemsize
+            return DeviceField(self.ctx, sub, self.dtype, _alloc=self._alloc, _offset=self._offset + k * stride)
+        if isinstance(idx, slice) and self.ndim >= 2 and idx.step in (None, 1) and not self._is_full(idx):
+            start, stop, _ = idx.indices(self.shape[0])
+            sub = (max(stop - start, 0),) + self.shape[1:]
+            stride = int(np.prod(self.shape[1:])) * self.dtype.itemsize
+            return DeviceField(self.ctx, sub, self.dtype, _alloc=self._alloc, _offset=self._offset + start * stride)
+        return self.get()[idx]
+
+    def __setitem__(self, idx, values):
+        if self._is_full(idx):
+            if isinstance(values, DeviceField):
+                if values.shape != self.shape or values.dtype != self.dtype:
+                    raise ValueError("shape / dtype mismatch in device copy")
+                call("smi_memcpy_d2d", self.ctx.handle, self.ptr, values.ptr, self.nbytes)
+            else:
+                self.set(values)
+            return
+        host = self.get()
+        host[idx] = np.asarray(values)
+        self.set(host)
+
+    def copy(self):
+        out = DeviceField(self.ctx, self.shape, self.dtype, zero=False)
+        call("smi_memcpy_d2d", self.ctx.handle, out.ptr, self.ptr, self.nbytes)
+        return out
+
+    def fill(self, value):
+        self.set(value)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __repr__(self):
+        return f"DeviceField(shape={self.shape}, dtype={self.dtype}, device={self.ctx.device})"
+
+
+def as_ptr(x):
+    """Device pointer of a DeviceField argument."""
+    if isinstance(x, DeviceField):
+        return x.ptr
+    raise TypeError(
+        f"expected a DeviceField (device-resident array), got {type(x).__name__}; "
+        "allocate fields through the simulator / DeviceContext"
+    )

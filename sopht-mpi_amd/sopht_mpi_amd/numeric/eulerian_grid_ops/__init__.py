@@ -1,0 +1,287 @@
+"""Eulerian grid operators with the reference's generator API
+(sopht_mpi/numeric/eulerian_grid_ops/__init__.py:1-5): every ``gen_*`` returns a callable
+that takes DeviceField arguments by keyword, carries ``.kernel_support`` and validates
+ghost size / arguments at generation time with the reference's exception types.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ... import _lib
+from ..._lib import call, darray
+from ...device import as_ptr
+from ...utils import check_valid_ghost_size_and_kernel_support
+
+
+def _support(gen, fn, kernel_support, ghost_exchange_communicator):
+    gen.kernel_support = kernel_support
+    fn.kernel_support = kernel_support
+    check_valid_ghost_size_and_kernel_support(ghost_exchange_communicator.ghost_size, kernel_support)
+    return fn
+
+
+def _check_field_type(field_type):
+    if field_type != "scalar" and field_type != "vector":
+        raise ValueError("Invalid field type")
+
+
+# ------------------------------------------------------------------ diffusion
+def gen_diffusion_flux_pyst_mpi_kernel_3d(real_t, mpi_construct, ghost_exchange_communicator, field_type="scalar"):
+    """stencil_ops_3d/diffusion_flux_mpi_3d.py:10-228."""
+    _check_field_type(field_type)
+    ctx = ghost_exchange_communicator.ctx
+
+    if field_type == "scalar":
+
+        def diffusion_flux_pyst_mpi_kernel_3d(diffusion_flux, field, prefactor):
+            call("smi_diffusion_flux", ctx.handle, as_ptr(diffusion_flux), as_ptr(field), float(prefactor), 1)
+
+        fn = diffusion_flux_pyst_mpi_kernel_3d
+    else:
+
+        def vector_field_diffusion_flux_pyst_mpi_kernel_3d(vector_field_diffusion_flux, vector_field, prefactor):
+            call("smi_diffusion_flux", ctx.handle, as_ptr(vector_field_diffusion_flux), as_ptr(vector_field),
+                 float(prefactor), 3)
+
+        fn = vector_field_diffusion_flux_pyst_mpi_kernel_3d
+    return _support(gen_diffusion_flux_pyst_mpi_kernel_3d, fn, 1, ghost_exchange_communicator)
+
+
+def gen_diffusion_timestep_euler_forward_pyst_mpi_kernel_3d(real_t, mpi_construct, ghost_exchange_communicator,
+                                                            field_type="scalar"):
+    """stencil_ops_3d/diffusion_timestep_mpi_3d.py:11-92."""
+    _check_field_type(field_type)
+    ctx = ghost_exchange_communicator.ctx
+
+    if field_type == "scalar":
+
+        def diffusion_timestep_euler_forward_pyst_mpi_kernel_3d(field, diffusion_flux, nu_dt_by_dx2):
+            call("smi_diffusion_timestep", ctx.handle, as_ptr(field), as_ptr(diffusion_flux), float(nu_dt_by_dx2), 1)
+
+        fn = diffusion_timestep_euler_forward_pyst_mpi_kernel_3d
+    else:
+
+        def vector_field_diffusion_timestep_euler_forward_pyst_mpi_kernel_3d(vector_field, diffusion_flux,
+                                                                             nu_dt_by_dx2):
+            call("smi_diffusion_timestep", ctx.handle, as_ptr(vector_field), as_ptr(diffusion_flux),
+                 float(nu_dt_by_dx2), 3)
+
+        fn = vector_field_diffusion_timestep_euler_forward_pyst_mpi_kernel_3d
+    return _support(gen_diffusion_timestep_euler_forward_pyst_mpi_kernel_3d, fn, 1, ghost_exchange_communicator)
+
+
+# ------------------------------------------------------------------ advection (ENO3)
+def gen_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d(
+    real_t, mpi_construct, ghost_exchange_communicator, field_type="scalar"
+):
+    """stencil_ops_3d/advection_timestep_mpi_3d.py:12-95."""
+    _check_field_type(field_type)
+    ctx = ghost_exchange_communicator.ctx
+
+    if field_type == "scalar":
+
+        def advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d(field, advection_flux, velocity,
+                                                                                  dt_by_dx):
+            call("smi_advection_timestep_eno3", ctx.handle, as_ptr(field), as_ptr(advection_flux), as_ptr(velocity),
+                 float(dt_by_dx), 1)
+
+        fn = advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d
+    else:
+
+        def vector_field_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d(
+            vector_field, advection_flux, velocity, dt_by_dx
+        ):
+            call("smi_advection_timestep_eno3", ctx.handle, as_ptr(vector_field), as_ptr(advection_flux),
+                 as_ptr(velocity), float(dt_by_dx), 3)
+
+        fn = vector_field_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d
+    return _support(gen_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d, fn, 2,
+                    ghost_exchange_communicator)
+
+
+# ------------------------------------------------------------------ curl family
+def gen_update_vorticity_from_velocity_forcing_pyst_mpi_kernel_3d(real_t, mpi_construct,
+                                                                  ghost_exchange_communicator):
+    """stencil_ops_3d/update_vorticity_from_velocity_forcing_mpi_3d.py:9-178."""
+    ctx = ghost_exchange_communicator.ctx
+
+    def update_vorticity_from_velocity_forcing_pyst_mpi_kernel_3d(vorticity_field, velocity_forcing_field,
+                                                                  prefactor):
+        call("smi_update_vorticity_from_velocity_forcing", ctx.handle, as_ptr(vorticity_field),
+             as_ptr(velocity_forcing_field), float(prefactor))
+
+    return _support(gen_update_vorticity_from_velocity_forcing_pyst_mpi_kernel_3d,
+                    update_vorticity_from_velocity_forcing_pyst_mpi_kernel_3d, 1, ghost_exchange_communicator)
+
+
+def gen_curl_pyst_mpi_kernel_3d(real_t, mpi_construct, ghost_exchange_communicator):
+    """stencil_ops_3d/curl_mpi_3d.py:10-196."""
+    ctx = ghost_exchange_communicator.ctx
+
+    def curl_pyst_mpi_kernel_3d(curl, field, prefactor):
+        call("smi_curl", ctx.handle, as_ptr(curl), as_ptr(field), float(prefactor))
+
+    return _support(gen_curl_pyst_mpi_kernel_3d, curl_pyst_mpi_kernel_3d, 1, ghost_exchange_communicator)
+
+
+def gen_divergence_pyst_mpi_kernel_3d(real_t, mpi_construct, ghost_exchange_communicator):
+    """stencil_ops_3d/divergence_mpi_3d.py:10-200."""
+    ctx = ghost_exchange_communicator.ctx
+
+    def divergence_pyst_mpi_kernel_3d(divergence, field, inv_dx):
+        call("smi_divergence", ctx.handle, as_ptr(divergence), as_ptr(field), float(real_t(inv_dx)))
+
+    return _support(gen_divergence_pyst_mpi_kernel_3d, divergence_pyst_mpi_kernel_3d, 1,
+                    ghost_exchange_communicator)
+
+
+# ------------------------------------------------------------------ penalise boundary
+def penalty_factor_tables(width, dx, x_grid_field, y_grid_field, z_grid_field, ghost_size, real_t):
+    """Sine factors of penalise_field_boundary_mpi_3d.py:50-57, 78-80, 92-94 for the low and
+    high bands of each axis, evaluated on the host in ``real_t`` from the position field."""
+    g, w = ghost_size, ghost_size + width
+    real_t = np.dtype(real_t).type
+    x = np.asarray(x_grid_field[g, g, :], dtype=real_t)
+    y = np.asarray(y_grid_field[g, :, g], dtype=real_t)
+    z = np.asarray(z_grid_field[:, g, g], dtype=real_t)
+    sine_prefactor = real_t((np.pi / 2) / (width * dx))
+    lo, hi = [], []
+    for c in (x, y, z):
+        start, end = c[g], c[-(g + 1)]
+        lo.append(np.sin(sine_prefactor * (c[:w] - start)).astype(real_t))
+        hi.append(np.sin(sine_prefactor * (end - c[-w:])).astype(real_t))
+    return np.concatenate(lo).astype(np.float64), np.concatenate(hi).astype(np.float64)
+
+
+def gen_penalise_field_boundary_pyst_mpi_kernel_3d(width, dx, x_grid_field, y_grid_field, z_grid_field, real_t,
+                                                   mpi_construct, ghost_exchange_communicator, field_type="scalar"):
+    """stencil_ops_3d/penalise_field_boundary_mpi_3d.py:9-269."""
+    if width < 0 or not isinstance(width, (int, np.integer)):
+        raise ValueError("invalid zone width")
+    _check_field_type(field_type)
+    gen_penalise_field_boundary_pyst_mpi_kernel_3d.kernel_support = 0
+    ctx = ghost_exchange_communicator.ctx
+    ncomp = 1 if field_type == "scalar" else 3
+    if width == 0:
+        if field_type == "scalar":
+
+            def penalise_field_boundary_pyst_mpi_kernel_3d(field):
+                pass
+
+        else:
+
+            def penalise_field_boundary_pyst_mpi_kernel_3d(vector_field):
+                pass
+
+        penalise_field_boundary_pyst_mpi_kernel_3d.kernel_support = 0
+        return penalise_field_boundary_pyst_mpi_kernel_3d
+
+    lo, hi = penalty_factor_tables(width, dx, x_grid_field, y_grid_field, z_grid_field,
+                                   ghost_exchange_communicator.ghost_size, real_t)
+    lo_c, hi_c = darray(lo), darray(hi)
+
+    if field_type == "scalar":
+
+        def penalise_field_boundary_pyst_mpi_kernel_3d(field):
+            call("smi_penalise_boundary", ctx.handle, as_ptr(field), ncomp, int(width), lo_c, hi_c)
+
+        fn = penalise_field_boundary_pyst_mpi_kernel_3d
+    else:
+
+        def penalise_vector_field_boundary_pyst_mpi_kernel_3d(vector_field):
+            call("smi_penalise_boundary", ctx.handle, as_ptr(vector_field), ncomp, int(width), lo_c, hi_c)
+
+        fn = penalise_vector_field_boundary_pyst_mpi_kernel_3d
+    fn.kernel_support = 0
+    fn.factor_tables = (lo, hi)
+    return fn
+
+
+# ------------------------------------------------------------------ Laplacian filter
+def gen_laplacian_filter_mpi_kernel_3d(mpi_construct, ghost_exchange_communicator, filter_order, filter_flux_buffer,
+                                       field_buffer, real_t, field_type="scalar", filter_type="multiplicative",
+                                       filter_flux_buffer_boundary_width=1):
+    """stencil_ops_3d/laplacian_filter_mpi_3d.py:14-421."""
+    if filter_order < 0 or not isinstance(filter_order, (int, np.integer)):
+        raise ValueError("Invalid filter order")
+    if filter_flux_buffer_boundary_width <= 0 or not isinstance(filter_flux_buffer_boundary_width, (int, np.integer)):
+        raise ValueError("Invalid value for filter flux buffer boundary zone")
+    if filter_flux_buffer_boundary_width != 1:
+        raise NotImplementedError("only filter_flux_buffer_boundary_width=1 (the reference default) is supported")
+    types = {"multiplicative": _lib.SMI_FILTER_MULTIPLICATIVE, "convolution": _lib.SMI_FILTER_CONVOLUTION}
+    if filter_type not in types:
+        raise ValueError("Invalid filter type")
+    if field_type not in ("scalar", "vector"):
+        raise ValueError("Invalid field type")
+    ctx = ghost_exchange_communicator.ctx
+    ftype = types[filter_type]
+
+    if field_type == "scalar":
+
+        def scalar_field_filter_mpi_kernel_3d(scalar_field):
+            call("smi_laplacian_filter", ctx.handle, as_ptr(scalar_field), 1, as_ptr(filter_flux_buffer),
+                 as_ptr(field_buffer), int(filter_order), ftype)
+
+        fn = scalar_field_filter_mpi_kernel_3d
+    else:
+
+        def vector_field_filter_kernel_3d(vector_field):
+            call("smi_laplacian_filter", ctx.handle, as_ptr(vector_field), 3, as_ptr(filter_flux_buffer),
+                 as_ptr(field_buffer), int(filter_order), ftype)
+
+        fn = vector_field_filter_kernel_3d
+    return _support(gen_laplacian_filter_mpi_kernel_3d, fn, 1, ghost_exchange_communicator)
+
+
+# ------------------------------------------------------------------ Poisson
+class UnboundedPoissonSolverMPI3D:
+    """poisson_solver_3d/UnboundedPoissonSolverMPI3D.py:14-187.
+
+    ``backend``: "rocfft" restates the reference literally on one GPU (zero-padded doubled
+    domain through rocFFT); "pruned" uses the library's own zero-padding-aware FFT passes and
+    is the only one that runs on several slabs.  Default: pruned when available for the grid.
+    """
+
+    def __init__(self, grid_size_z, grid_size_y, grid_size_x, mpi_construct, ghost_size, x_range=1.0,
+                 real_t=np.float64, backend=None):
+        self.mpi_construct = mpi_construct
+        self.grid_size_z, self.grid_size_y, self.grid_size_x = grid_size_z, grid_size_y, grid_size_x
+        self.x_range = x_range
+        self.y_range = x_range * (grid_size_y / grid_size_x)
+        self.z_range = x_range * (grid_size_z / grid_size_x)
+        self.real_t = real_t
+        self.dx = real_t(x_range / grid_size_x)
+        self.ctx = mpi_construct.device_context(ghost_size)
+        names = {"rocfft": _lib.SMI_POISSON_ROCFFT, "pruned": _lib.SMI_POISSON_PRUNED}
+        order = [backend] if backend is not None else ["pruned", "rocfft"]
+        err = None
+        self.handle = None
+        for name in order:
+            h = C.c_void_p()
+            try:
+                call("smi_poisson_create", C.byref(h), self.ctx.handle, int(grid_size_z), int(grid_size_y),
+                     int(grid_size_x), float(self.dx), float(x_range), names[name])
+                self.handle, self.backend = h, name
+                break
+            except _lib.SophtMIError as exc:
+                err = exc
+        if self.handle is None:
+            raise err
+
+    def solve(self, solution_field, rhs_field):
+        """-del^2(solution_field) = rhs_field, unbounded domain (:133-167)."""
+        call("smi_poisson_solve", self.handle, as_ptr(solution_field), as_ptr(rhs_field))
+
+    def vector_field_solve(self, solution_vector_field, rhs_vector_field):
+        """:169-187."""
+        call("smi_poisson_vector_solve", self.handle, as_ptr(solution_vector_field), as_ptr(rhs_vector_field))
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.ctx.handle:
+                _lib.lib.smi_poisson_destroy(self.handle)
+        except Exception:
+            pass
+
+
+__all__ = [n for n in dir() if n.startswith("gen_")] + ["UnboundedPoissonSolverMPI3D", "penalty_factor_tables"]

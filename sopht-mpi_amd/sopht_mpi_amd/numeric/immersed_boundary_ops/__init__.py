@@ -1,0 +1,258 @@
+"""Immersed-boundary operators with the reference's names
+(sopht_mpi/numeric/immersed_boundary_ops/__init__.py:1-8)."""
+import numpy as np
+
+from ... import _lib
+from ..._lib import call, i64array
+from ...device import DeviceField, as_ptr
+from ...utils import MPILagrangianFieldCommunicator3D
+
+_KERNEL_TYPES = {"cosine": _lib.SMI_DELTA_COSINE, "peskin": _lib.SMI_DELTA_PESKIN}
+
+
+class EulerianLagrangianGridCommunicatorMPI3D:
+    """EulerianLagrangianGridCommunicatorMPI3D.py:7-113.  The four kernels take device arrays
+    positionally, in the reference's layouts: index (3, M) int64 (x, y, z), support
+    (3, 4, 4, 4, M) float64, weights (4, 4, 4, M) float64, Lagrangian fields (3, M) or (M,)."""
+
+    def __init__(self, dx, eul_grid_coord_shift, interp_kernel_width, real_t, mpi_construct, ghost_size,
+                 n_components=1, interp_kernel_type="cosine"):
+        if ghost_size < interp_kernel_width:
+            raise ValueError(
+                f"ghost size ({ghost_size}) needs to be >= interp kernel width ({interp_kernel_width})"
+            )
+        if interp_kernel_width != 2:
+            raise AssertionError("Interpolation kernel inconsistent with interpolation kernel width!")
+        if n_components not in (1, 3):
+            raise AssertionError("invalid number of components for interpolation!")
+        if interp_kernel_type not in _KERNEL_TYPES:
+            raise ValueError(
+                "Invalid interpolation kernel type. Currently supported types are 'cosine' and 'peskin'."
+            )
+        self.mpi_construct = mpi_construct
+        self.ctx = mpi_construct.device_context(ghost_size)
+        self.dx = float(dx)
+        self.coord_shift = float(eul_grid_coord_shift)
+        self.n_components = n_components
+        self.kernel_type = _KERNEL_TYPES[interp_kernel_type]
+        # :41-46, x, y, z order
+        self.mpi_substart_idx = np.flip(mpi_construct.grid.coords * mpi_construct.local_grid_size)
+        self.mpi_local_substart_coord_shift = self.mpi_substart_idx - ghost_size
+        self._substart = i64array(self.mpi_substart_idx)
+
+    def local_eulerian_grid_support_of_lagrangian_grid_kernel(self, local_eul_grid_support_of_lag_grid,
+                                                              nearest_eul_grid_index_to_lag_grid, lag_positions):
+        m = lag_positions.shape[-1]
+        call("smi_ib_support", self.ctx.handle, as_ptr(local_eul_grid_support_of_lag_grid),
+             as_ptr(nearest_eul_grid_index_to_lag_grid), as_ptr(lag_positions), m, self.dx, self.coord_shift,
+             self._substart)
+
+    def interpolation_weights_kernel(self, interp_weights, local_eul_grid_support_of_lag_grid):
+        m = interp_weights.shape[-1]
+        call("smi_ib_weights", self.ctx.handle, as_ptr(interp_weights), as_ptr(local_eul_grid_support_of_lag_grid),
+             m, self.dx, self.kernel_type)
+
+    def eulerian_to_lagrangian_grid_interpolation_kernel(self, lag_grid_field, eul_grid_field, interp_weights,
+                                                         nearest_eul_grid_index_to_lag_grid):
+        m = lag_grid_field.shape[-1]
+        call("smi_ib_interpolate", self.ctx.handle, as_ptr(lag_grid_field), as_ptr(eul_grid_field),
+             as_ptr(interp_weights), as_ptr(nearest_eul_grid_index_to_lag_grid), m, self.n_components, self.dx)
+
+    def lagrangian_to_eulerian_grid_interpolation_kernel_without_ghost_sum(self, eul_grid_field, lag_grid_field,
+                                                                           interp_weights,
+                                                                           nearest_eul_grid_index_to_lag_grid):
+        m = lag_grid_field.shape[-1]
+        call("smi_ib_spread", self.ctx.handle, as_ptr(eul_grid_field), as_ptr(lag_grid_field),
+             as_ptr(interp_weights), as_ptr(nearest_eul_grid_index_to_lag_grid), m, self.n_components)
+
+    def eulerian_grid_ghost_sum(self, local_field):
+        call("smi_ghost_sum", self.ctx.handle, as_ptr(local_field), self.n_components)
+
+    def lagrangian_to_eulerian_grid_interpolation_kernel(self, eul_grid_field, lag_grid_field, interp_weights,
+                                                         nearest_eul_grid_index_to_lag_grid):
+        """:99-113: spread, then add ghost contributions to the neighbours and zero the ghosts."""
+        self.lagrangian_to_eulerian_grid_interpolation_kernel_without_ghost_sum(
+            eul_grid_field, lag_grid_field, interp_weights, nearest_eul_grid_index_to_lag_grid
+        )
+        self.eulerian_grid_ghost_sum(local_field=eul_grid_field)
+
+
+class VirtualBoundaryForcingMPI:
+    """VirtualBoundaryForcingMPI.py:21-459 (3D).
+
+    Global Lagrangian arrays (``global_lag_grid_*``) are host numpy arrays owned by the master
+    rank as in the reference; the ``local_lag_grid_*`` arrays of this slab's nodes live on the
+    device.  Steps 1-5 of the interaction run as one fused kernel (index, delta weights,
+    E->L interpolation, mismatch, penalty force); the spread is a second kernel.
+    """
+
+    def __init__(self, mpi_construct, ghost_size, virtual_boundary_stiffness_coeff, virtual_boundary_damping_coeff,
+                 grid_dim, dx, eul_grid_coord_shift=None, interp_kernel_width=None,
+                 enable_eul_grid_forcing_reset=True, start_time=0.0, master_rank=0,
+                 global_lag_grid_position_field=None, assume_data_locality=False, interp_kernel_type="cosine"):
+        if grid_dim != 2 and grid_dim != 3:
+            raise ValueError("Invalid grid dimensions for virtual boundary forcing!")
+        if grid_dim != 3:
+            raise NotImplementedError("the GPU immersed-boundary path is 3D only")
+        self.grid_dim = grid_dim
+        self.virtual_boundary_stiffness_coeff = virtual_boundary_stiffness_coeff
+        self.virtual_boundary_damping_coeff = virtual_boundary_damping_coeff
+        self.time = start_time
+        self.assume_data_locality = assume_data_locality
+        self.eul_grid_real_t = mpi_construct.real_t
+        self.lag_grid_real_t = np.dtype(np.float64)
+        if eul_grid_coord_shift is None:
+            eul_grid_coord_shift = self.eul_grid_real_t(dx / 2)
+        self.interp_kernel_width = 2 if interp_kernel_width is None else interp_kernel_width
+        self.ghost_size = ghost_size
+        if self.interp_kernel_width > ghost_size:
+            raise ValueError(
+                f"Field ghost size {ghost_size} needs to be larger than "
+                f"interpolation kernel width {self.interp_kernel_width}"
+            )
+        self.mpi_construct = mpi_construct
+        self.master_rank = master_rank
+        self.dx = float(dx)
+        self.eul_lag_grid_communicator = EulerianLagrangianGridCommunicatorMPI3D(
+            dx=dx, eul_grid_coord_shift=eul_grid_coord_shift, interp_kernel_width=self.interp_kernel_width,
+            real_t=self.eul_grid_real_t, n_components=grid_dim, mpi_construct=mpi_construct, ghost_size=ghost_size,
+            interp_kernel_type=interp_kernel_type,
+        )
+        self.ctx = self.eul_lag_grid_communicator.ctx
+        if not assume_data_locality:
+            self.mpi_lagrangian_field_communicator = MPILagrangianFieldCommunicator3D(
+                eul_grid_dx=dx, eul_grid_coord_shift=eul_grid_coord_shift, mpi_construct=mpi_construct,
+                master_rank=master_rank, real_t=np.float64,
+            )
+            self.mpi_lagrangian_field_communicator.map_lagrangian_nodes_based_on_position(
+                global_lag_positions=global_lag_grid_position_field
+            )
+            self.local_num_lag_nodes = self.mpi_lagrangian_field_communicator.local_num_lag_nodes
+            self.global_num_lag_nodes = self.mpi_lagrangian_field_communicator.rank_address.shape[-1]
+        else:
+            self.local_num_lag_nodes = global_lag_grid_position_field.shape[-1]
+            self.global_num_lag_nodes = self.local_num_lag_nodes
+        self._init_local_buffers(self.local_num_lag_nodes)
+        self._init_global_buffers()
+        self.enable_eul_grid_forcing_reset = enable_eul_grid_forcing_reset
+        if enable_eul_grid_forcing_reset:
+            self.compute_interaction_forcing = (
+                self.compute_interaction_force_on_eul_and_lag_grid_with_eul_grid_forcing_reset
+            )
+        else:
+            self.compute_interaction_forcing = self.compute_interaction_force_on_eul_and_lag_grid
+
+    # ---------------------------------------------------------------- buffers
+    def _init_global_buffers(self):
+        shape = (self.grid_dim, self.global_num_lag_nodes)
+        self.global_lag_grid_position_mismatch_field = np.zeros(shape, dtype=np.float64)
+        self.global_lag_grid_velocity_mismatch_field = np.zeros(shape, dtype=np.float64)
+        self.global_lag_grid_forcing_field = np.zeros(shape, dtype=np.float64)
+
+    def _init_local_buffers(self, num_lag_nodes):
+        """:201-236, device resident.  Support / weights arrays are not materialised by the
+        fused path; ask the communicator's kernels for them when needed."""
+        shape = (self.grid_dim, num_lag_nodes)
+        z = lambda: self.ctx.zeros(shape, np.float64)  # noqa: E731
+        self.local_lag_grid_flow_velocity_field = z()
+        self.local_lag_grid_position_mismatch_field = z()
+        self.local_lag_grid_velocity_mismatch_field = z()
+        self.local_lag_grid_forcing_field = z()
+        self.local_lag_grid_position_field = z()
+        self.local_lag_grid_velocity_field = z()
+
+    def update_buffers(self, global_lag_grid_position_field):
+        """:238-276: re-map nodes to slabs; re-scatter the mismatch state when ownership changed."""
+        comm = self.mpi_lagrangian_field_communicator
+        old_address = comm.rank_address.copy()
+        local_pm = self.local_lag_grid_position_mismatch_field.get()
+        local_vm = self.local_lag_grid_velocity_mismatch_field.get()
+        comm.gather_local_field(self.global_lag_grid_position_mismatch_field, local_pm)
+        comm.gather_local_field(self.global_lag_grid_velocity_mismatch_field, local_vm)
+        comm.map_lagrangian_nodes_based_on_position(global_lag_grid_position_field)
+        changed = not np.array_equal(old_address, comm.rank_address)
+        if changed:
+            self.local_num_lag_nodes = comm.local_num_lag_nodes
+            self._init_local_buffers(self.local_num_lag_nodes)
+            pm = np.zeros((self.grid_dim, self.local_num_lag_nodes))
+            vm = np.zeros_like(pm)
+            comm.scatter_global_field(pm, self.global_lag_grid_position_mismatch_field)
+            comm.scatter_global_field(vm, self.global_lag_grid_velocity_mismatch_field)
+            self.local_lag_grid_position_mismatch_field.set(pm)
+            self.local_lag_grid_velocity_mismatch_field.set(vm)
+
+    # ---------------------------------------------------------------- interaction
+    def _upload_lagrangian_state(self, global_lag_grid_position_field, global_lag_grid_velocity_field):
+        m = self.local_num_lag_nodes
+        if self.assume_data_locality or self.mpi_construct.size == 1:
+            pos = np.asarray(global_lag_grid_position_field, dtype=np.float64)
+            vel = np.asarray(global_lag_grid_velocity_field, dtype=np.float64)
+        else:
+            comm = self.mpi_lagrangian_field_communicator
+            pos = np.zeros((self.grid_dim, m))
+            vel = np.zeros((self.grid_dim, m))
+            comm.scatter_global_field(pos, global_lag_grid_position_field)
+            comm.scatter_global_field(vel, global_lag_grid_velocity_field)
+        if m:
+            self.local_lag_grid_position_field.set(pos)
+            self.local_lag_grid_velocity_field.set(vel)
+
+    def compute_interaction_force_on_lag_grid(self, local_eul_grid_velocity_field, global_lag_grid_position_field,
+                                              global_lag_grid_velocity_field):
+        """:333-406."""
+        multi = self.mpi_construct.size > 1
+        if not self.assume_data_locality and multi:
+            self.update_buffers(global_lag_grid_position_field)
+        elif not self.assume_data_locality:
+            # one slab owns every node: only the inside-the-domain check of the mapping remains
+            self.mpi_lagrangian_field_communicator._compute_lag_nodes_rank_address(global_lag_grid_position_field)
+        self._upload_lagrangian_state(global_lag_grid_position_field, global_lag_grid_velocity_field)
+        comm = self.eul_lag_grid_communicator
+        call("smi_ib_forcing_fused", self.ctx.handle, as_ptr(self.local_lag_grid_forcing_field),
+             as_ptr(self.local_lag_grid_velocity_mismatch_field), as_ptr(self.local_lag_grid_flow_velocity_field),
+             as_ptr(self.local_lag_grid_position_mismatch_field), as_ptr(self.local_lag_grid_position_field),
+             as_ptr(self.local_lag_grid_velocity_field), as_ptr(local_eul_grid_velocity_field),
+             self.local_num_lag_nodes, comm.dx, comm.coord_shift, comm._substart,
+             float(self.virtual_boundary_stiffness_coeff), float(self.virtual_boundary_damping_coeff),
+             comm.kernel_type)
+        if not self.assume_data_locality and multi:
+            self.mpi_lagrangian_field_communicator.gather_local_field(
+                self.global_lag_grid_forcing_field, self.local_lag_grid_forcing_field.get()
+            )
+        else:
+            self.global_lag_grid_forcing_field[...] = self.local_lag_grid_forcing_field.get()
+
+    def compute_interaction_force_on_eul_and_lag_grid(self, local_eul_grid_forcing_field,
+                                                      local_eul_grid_velocity_field, global_lag_grid_position_field,
+                                                      global_lag_grid_velocity_field):
+        """:408-429."""
+        self.compute_interaction_force_on_lag_grid(
+            local_eul_grid_velocity_field, global_lag_grid_position_field, global_lag_grid_velocity_field
+        )
+        comm = self.eul_lag_grid_communicator
+        call("smi_ib_spread_fused", self.ctx.handle, as_ptr(local_eul_grid_forcing_field),
+             as_ptr(self.local_lag_grid_forcing_field), as_ptr(self.local_lag_grid_position_field),
+             self.local_num_lag_nodes, comm.dx, comm.coord_shift, comm._substart, comm.kernel_type)
+        comm.eulerian_grid_ghost_sum(local_field=local_eul_grid_forcing_field)
+
+    def compute_interaction_force_on_eul_and_lag_grid_with_eul_grid_forcing_reset(
+        self, local_eul_grid_forcing_field, local_eul_grid_velocity_field, global_lag_grid_position_field,
+        global_lag_grid_velocity_field,
+    ):
+        """:431-450."""
+        call("smi_set_fixed_val", self.ctx.handle, as_ptr(local_eul_grid_forcing_field), self.grid_dim,
+             _lib.darray([0.0] * self.grid_dim))
+        self.compute_interaction_force_on_eul_and_lag_grid(
+            local_eul_grid_forcing_field, local_eul_grid_velocity_field, global_lag_grid_position_field,
+            global_lag_grid_velocity_field,
+        )
+
+    def time_step(self, dt):
+        """:452-459."""
+        n = self.grid_dim * self.local_num_lag_nodes
+        call("smi_ib_mismatch_step", self.ctx.handle, as_ptr(self.local_lag_grid_position_mismatch_field),
+             as_ptr(self.local_lag_grid_velocity_mismatch_field), n, float(dt))
+        self.time += dt
+
+
+__all__ = ["EulerianLagrangianGridCommunicatorMPI3D", "VirtualBoundaryForcingMPI"]

@@ -1,0 +1,6 @@
+from .immersed_body_forcing_grid import EmptyForcingGrid, ImmersedBodyForcingGrid, PrescribedForcingGrid  # noqa: F401
+from .immersed_body_flow_interaction import (  # noqa: F401
+    ImmersedBodyFlowInteractionMPI,
+    RigidBodyFlowInteractionMPI,
+    CosseratRodFlowInteraction,
+)

@@ -1,0 +1,244 @@
+"""Distributed plumbing with the reference's names (sopht_mpi/utils/mpi_utils_3d.py).
+
+``MPIConstruct3D`` describes the z-slab decomposition (one process per GPU),
+``MPIGhostCommunicator3D`` the halo exchange, ``MPIFieldCommunicator3D`` host <-> device
+scatter / gather of global arrays, ``MPILagrangianFieldCommunicator3D`` the ownership
+map of Lagrangian nodes.
+"""
+import ctypes as C
+import logging
+import os
+
+import numpy as np
+
+from .. import _lib
+from .._lib import call
+from ..device import DeviceContext, DeviceField, as_ptr
+from ..world import get_world
+
+logger = logging.getLogger("sopht_mpi_amd")
+PROC_NULL = -1  # stands for MPI.PROC_NULL in previous_grid_along / next_grid_along
+
+
+def check_valid_ghost_size_and_kernel_support(ghost_size, kernel_support):
+    """utils/mpi_utils.py:17-24."""
+    if ghost_size < kernel_support:
+        raise ValueError(
+            f"Inconsistent ghost_size={ghost_size} and kernel_support={kernel_support}. "
+            "Need to have ghost_size >= kernel_support"
+        )
+
+
+class _Grid:
+    """The part of the reference's Cartesian communicator (``mpi_construct.grid``) users touch."""
+
+    def __init__(self, construct):
+        self._c = construct
+        self.coords = np.array([construct.rank, 0, 0])
+
+    def Get_size(self):
+        return self._c.size
+
+    def Get_rank(self):
+        return self._c.rank
+
+    def allreduce(self, value, op="sum"):
+        return self._c.world.allreduce(value, op)
+
+    def bcast(self, obj, root=0):
+        return self._c.world.bcast_object(obj, root)
+
+    def Get_cart_rank(self, coords):
+        return int(coords[0])
+
+
+class MPIConstruct3D:
+    """utils/mpi_utils_3d.py:7-83 restricted to z-slabs.
+
+    ``rank_distribution`` follows the reference: 0 = distribute, 1 = keep aligned.  With more
+    than one rank only slab layouts along z, ``(0, 1, 1)`` (or None), are accepted here;
+    pencil layouts raise.  Uneven division raises RuntimeError like the reference (:51-57).
+    """
+
+    def __init__(self, grid_size_z, grid_size_y, grid_size_x, periodic_domain=False, real_t=np.float64,
+                 rank_distribution=None, world=None):
+        self.grid_dim = 3
+        self.real_t = real_t
+        if periodic_domain:
+            raise NotImplementedError("periodic domains are not supported")
+        self.periodic_domain = False
+        self.world = get_world() if world is None else world
+        self.size, self.rank = self.world.size, self.world.rank
+        if rank_distribution is None:
+            rank_distribution = [0, 1, 1] if self.size > 1 else [0, 0, 1]
+        self.rank_distribution = list(rank_distribution)
+        if self.size > 1 and (self.rank_distribution[1] != 1 or self.rank_distribution[2] != 1):
+            raise NotImplementedError(
+                f"rank_distribution {self.rank_distribution}: only z-slab decomposition (0, 1, 1) is supported"
+            )
+        self.grid_topology = [self.size, 1, 1]
+        self.global_grid_size = np.array((grid_size_z, grid_size_y, grid_size_x))
+        if np.any(self.global_grid_size % self.grid_topology):
+            logger.error("Cannot divide grid evenly to processors in x, y and/or z directions!")
+            raise RuntimeError("Invalid domain decomposition")
+        self.local_grid_size = (self.global_grid_size / self.grid_topology).astype(int)
+        self.grid = _Grid(self)
+        self.previous_grid_along = np.array([self.rank - 1 if self.rank > 0 else PROC_NULL, PROC_NULL, PROC_NULL])
+        self.next_grid_along = np.array(
+            [self.rank + 1 if self.rank < self.size - 1 else PROC_NULL, PROC_NULL, PROC_NULL]
+        )
+        self._contexts = {}
+
+    def device_context(self, ghost_size):
+        """The GPU context of this slab for a ghost width (created once, shared by all operators)."""
+        ctx = self._contexts.get(ghost_size)
+        if ctx is None:
+            ctx = DeviceContext(self.local_grid_size, ghost_size, self.real_t, rank=self.rank, nranks=self.size,
+                                world=self.world)
+            if self.size > 1:
+                ndev = C.c_int(0)
+                call("smi_device_count", C.byref(ndev))
+                mode = os.environ.get("SOPHT_MI_TRANSPORT", "rccl" if ndev.value >= self.size else "host")
+                if mode == "rccl":
+                    ctx.init_rccl()
+                else:
+                    ctx.init_host_staged()
+            self._contexts[ghost_size] = ctx
+        return ctx
+
+
+class MPIGhostCommunicator3D:
+    """utils/mpi_utils_3d.py:86-1142.  ``full_exchange`` is accepted for compatibility: z-slabs
+    have no diagonal neighbours, and whole ghost planes travel anyway."""
+
+    def __init__(self, ghost_size, mpi_construct, full_exchange=True):
+        if ghost_size <= 0 or not isinstance(ghost_size, (int, np.integer)):
+            raise ValueError(f"Ghost size {ghost_size} needs to be an integer > 0 for calling ghost communication.")
+        self.ghost_size = int(ghost_size)
+        self.mpi_construct = mpi_construct
+        self.full_exchange = full_exchange
+        self.ctx = mpi_construct.device_context(self.ghost_size)
+
+    def exchange_scalar_field_init(self, local_field):
+        call("smi_halo_exchange", self.ctx.handle, as_ptr(local_field), 1)
+
+    def exchange_vector_field_init(self, local_vector_field):
+        call("smi_halo_exchange", self.ctx.handle, as_ptr(local_vector_field), local_vector_field.shape[0])
+
+    def exchange_finalise(self):
+        """Exchanges are stream-ordered with the kernels that consume them; nothing to wait for."""
+
+
+class MPIFieldCommunicator3D:
+    """utils/mpi_utils_3d.py:1145-1306: scatter / gather whole Eulerian fields between a global
+    host array on ``master_rank`` and the device slabs (interiors only, ghosts untouched)."""
+
+    def __init__(self, ghost_size, mpi_construct, master_rank=0):
+        self.mpi_construct = mpi_construct
+        self.ghost_size = ghost_size
+        self.master_rank = master_rank
+        g = ghost_size
+        self.inner_idx = (slice(g, -g),) * 3 if g > 0 else (slice(None),) * 3
+
+    def _slab(self, rank):
+        lz = self.mpi_construct.local_grid_size[0]
+        return slice(rank * lz, (rank + 1) * lz)
+
+    def scatter_global_scalar_field(self, local_field, global_field):
+        world = self.mpi_construct.world
+        data = world.bcast_object(global_field, root=self.master_rank) if world.size > 1 else global_field
+        host = local_field.get()
+        host[self.inner_idx] = np.asarray(data)[self._slab(self.mpi_construct.rank)]
+        local_field.set(host)
+
+    def gather_local_scalar_field(self, global_field, local_field):
+        world = self.mpi_construct.world
+        mine = local_field.get()[self.inner_idx]
+        if world.size == 1:
+            global_field[...] = mine
+            return
+        parts = [world.bcast_object(mine if world.rank == r else None, root=r) for r in range(world.size)]
+        if world.rank == self.master_rank:
+            global_field[...] = np.concatenate(parts, axis=0)
+
+    def scatter_global_vector_field(self, local_vector_field, global_vector_field):
+        for c in range(3):
+            self.scatter_global_scalar_field(
+                local_vector_field[c], None if global_vector_field is None else global_vector_field[c]
+            )
+
+    def gather_local_vector_field(self, global_vector_field, local_vector_field):
+        for c in range(3):
+            self.gather_local_scalar_field(
+                None if global_vector_field is None else global_vector_field[c], local_vector_field[c]
+            )
+
+
+class MPILagrangianFieldCommunicator3D:
+    """utils/mpi_utils_3d.py:1309-1459: which slab owns each Lagrangian node, and scatter /
+    gather of (3, M) Lagrangian arrays between the master rank and the owners."""
+
+    def __init__(self, eul_grid_dx, eul_grid_coord_shift, mpi_construct, master_rank=0, real_t=np.float64):
+        self.grid_dim = 3
+        self.mpi_construct = mpi_construct
+        self.master_rank = master_rank
+        self.rank = mpi_construct.rank
+        self.eul_subblock_dx = eul_grid_dx * mpi_construct.local_grid_size
+        self.eul_grid_coord_shift = eul_grid_coord_shift
+        self.real_t = real_t
+        self.rank_address = np.zeros(0, dtype=np.int32)
+        self.local_num_lag_nodes = 0
+
+    def _compute_lag_nodes_rank_address(self, global_lag_positions):
+        """:1352-1384 (slabs: only the z coordinate selects the owner)."""
+        topo = self.mpi_construct.grid_topology
+        cz = ((global_lag_positions[2, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[0]).astype(np.int32)
+        cy = ((global_lag_positions[1, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[1]).astype(np.int32)
+        cx = ((global_lag_positions[0, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[2]).astype(np.int32)
+        if np.any(cx >= topo[2]) or np.any(cy >= topo[1]) or np.any(cz >= topo[0]) or np.any(cz < 0):
+            logger.error("Lagrangian node is found outside of Eulerian domain!")
+            raise RuntimeError("Lagrangian node is found outside of Eulerian domain!")
+        return cz.astype(np.int32)
+
+    def map_lagrangian_nodes_based_on_position(self, global_lag_positions):
+        world = self.mpi_construct.world
+        if self.rank == self.master_rank:
+            if global_lag_positions.shape[0] != self.grid_dim:
+                raise RuntimeError(f"global_lag_positions needs to be shape ({self.grid_dim}, ...)")
+            rank_address = self._compute_lag_nodes_rank_address(global_lag_positions)
+        else:
+            rank_address = None
+        self.rank_address = world.bcast_object(rank_address, root=self.master_rank)
+        self.local_nodes_idx = np.where(self.rank_address == self.rank)
+        self.local_num_lag_nodes = int(np.count_nonzero(self.rank_address == self.rank))
+        self.slave_ranks_containing_lag_nodes = set(self.rank_address.tolist()) - {self.master_rank}
+
+    def scatter_global_field(self, local_lag_field, global_lag_field):
+        """Master's (3, M) host array -> every owner's (3, M_local) host array."""
+        world = self.mpi_construct.world
+        data = world.bcast_object(global_lag_field, root=self.master_rank) if world.size > 1 else global_lag_field
+        idx = np.where(self.rank_address == self.rank)[0]
+        local_lag_field[...] = np.asarray(data)[:, idx]
+
+    def gather_local_field(self, global_lag_field, local_lag_field):
+        world = self.mpi_construct.world
+        if world.size == 1:
+            global_lag_field[:, np.where(self.rank_address == self.rank)[0]] = local_lag_field
+            return
+        parts = [world.bcast_object(np.asarray(local_lag_field) if world.rank == r else None, root=r)
+                 for r in range(world.size)]
+        if self.rank == self.master_rank:
+            for r, part in enumerate(parts):
+                global_lag_field[:, np.where(self.rank_address == r)[0]] = part
+
+
+__all__ = [
+    "MPIConstruct3D",
+    "MPIGhostCommunicator3D",
+    "MPIFieldCommunicator3D",
+    "MPILagrangianFieldCommunicator3D",
+    "check_valid_ghost_size_and_kernel_support",
+    "logger",
+    "PROC_NULL",
+    "DeviceField",
+]

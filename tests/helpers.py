@@ -1,0 +1,27 @@
+"""Shared helpers of the GPU parity tests: tolerances and small factories."""
+import numpy as np
+
+# Floating-point parity bar.  north_star: "matching reference vorticity to rtol 1e-5" (f32).
+# Pointwise rtol is meaningless where a field crosses zero, so the bound is relative to the
+# largest magnitude of the expected array: |got - want| <= TOL * max|want|.
+TOL = {np.dtype(np.float32): 1e-5, np.dtype(np.float64): 1e-12}
+
+
+def assert_close(got, want, real_t, scale=None, factor=1.0, what=""):
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    ref = float(np.max(np.abs(want))) if scale is None else float(scale)
+    tol = factor * TOL[np.dtype(real_t)] * max(ref, np.finfo(np.float64).tiny)
+    err = float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64)))) if got.size else 0.0
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e} (scale {ref:.3e})"
+
+
+def make_ctx(smi, shape, ghost, real_t, rank=0, nranks=1):
+    from sopht_mpi_amd.device import DeviceContext
+
+    return DeviceContext(shape, ghost, real_t, rank=rank, nranks=nranks)
+
+
+def rand_field(rng, shape, real_t):
+    return rng.random(shape).astype(real_t) - real_t(0.5)

@@ -1,0 +1,128 @@
+"""GPU parity: whole flow steps of UnboundedFlowSimulator3D against the oracle, through the
+reference's own simulator API (operator-by-operator and fused), several steps in a row."""
+import numpy as np
+import pytest
+
+from helpers import assert_close
+from oracle.flow_3d import FlowSimulator3D as OracleSim
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob_vorticity(sim_shape, pos, rng, real_t):
+    """Smooth compact vorticity (a few Gaussian blobs), zero near the boundaries."""
+    x, y, z = pos
+    w = np.zeros((3,) + sim_shape, dtype=np.float64)
+    for _ in range(4):
+        c = rng.uniform(0.35, 0.65, 3)
+        amp = rng.uniform(-1, 1, 3)
+        r2 = (x - c[0]) ** 2 + (y - c[1] * y.max()) ** 2 + (z - c[2] * z.max()) ** 2
+        for k in range(3):
+            w[k] += amp[k] * np.exp(-r2 / (2 * 0.06**2))
+    return w.astype(real_t)
+
+
+def _pair(smi, n, flow_type, real_t, **kw):
+    from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
+
+    common = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, flow_type=flow_type, real_t=real_t,
+                  ghost_size=kw.pop("ghost_size", 2))
+    fused = kw.pop("fused_step", True)
+    backend = kw.pop("poisson_backend", None)
+    gpu = UnboundedFlowSimulator3D(fused_step=fused, poisson_backend=backend, **common, **kw)
+    cpu = OracleSim(**common, **kw)
+    return gpu, cpu
+
+
+@pytest.mark.parametrize("backend", ["rocfft", "pruned"])
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize(
+    "n,flow_type,free_stream,filt",
+    [
+        ((16, 16, 16), "navier_stokes", False, False),
+        ((16, 16, 32), "navier_stokes", True, False),
+        ((32, 32, 32), "navier_stokes_with_forcing", True, False),
+        ((16, 16, 16), "navier_stokes_with_forcing", True, True),
+    ],
+)
+def test_navier_stokes_steps(smi, n, flow_type, free_stream, filt, real_t, fused, backend):
+    from sopht_mpi_amd._lib import SophtMIError
+
+    rng = np.random.default_rng(11)
+    kw = dict(with_free_stream_flow=free_stream, filter_vorticity=filt)
+    if filt:
+        kw["filter_setting_dict"] = {"order": 1, "type": "multiplicative"}
+    try:
+        gpu, cpu = _pair(smi, n, flow_type, real_t, fused_step=fused, poisson_backend=backend, **kw)
+    except SophtMIError as exc:
+        if "not available" in str(exc) or "power of two" in str(exc):
+            pytest.skip(str(exc))
+        raise
+    assert gpu.unbounded_poisson_solver.backend == backend
+    w0 = _blob_vorticity(cpu.vorticity_field.shape[1:], cpu.position_field, rng, real_t)
+    gpu.vorticity_field[...] = w0
+    cpu.vorticity_field[...] = w0
+    fs = np.array([1.0, 0.5, -0.25])
+    gpu.compute_flow_velocity(free_stream_velocity=fs)
+    cpu.compute_flow_velocity(free_stream_velocity=fs)
+    assert_close(gpu.velocity_field.get(), cpu.velocity_field, real_t, factor=3.0, what="initial velocity")
+    for step in range(3):
+        dt_gpu = gpu.compute_stable_timestep(dt_prefac=0.5)
+        dt_cpu = cpu.compute_stable_timestep(dt_prefac=0.5)
+        assert abs(dt_gpu - dt_cpu) <= 1e-5 * dt_cpu
+        if flow_type == "navier_stokes_with_forcing":
+            forcing = (rng.random(cpu.velocity_field.shape) - 0.5).astype(real_t) * real_t(0.1)
+            gpu.eul_grid_forcing_field[...] = forcing
+            cpu.eul_grid_forcing_field[...] = forcing
+        gpu.time_step(dt=dt_cpu, free_stream_velocity=fs)
+        cpu.time_step(dt=dt_cpu, free_stream_velocity=fs)
+        g = gpu.ghost_size
+        inner = (slice(None),) + (slice(g, -g),) * 3
+        # north-star bar: vorticity to 1e-5 (relative to its maximum); errors of three steps add up
+        assert_close(gpu.vorticity_field.get()[inner], cpu.vorticity_field[inner], real_t, factor=1.0 + step,
+                     what=f"vorticity step {step}")
+        assert_close(gpu.velocity_field.get()[inner], cpu.velocity_field[inner], real_t, factor=3.0 + step,
+                     what=f"velocity step {step}")
+        assert_close(gpu.vorticity_field.get(), cpu.vorticity_field, real_t, factor=2.0 + step,
+                     what=f"vorticity incl. ghosts step {step}")
+    assert gpu.time == cpu.time
+    if flow_type == "navier_stokes_with_forcing":
+        assert not np.any(gpu.eul_grid_forcing_field.get())
+    assert abs(float(gpu.get_max_vorticity()) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(
+        float(cpu.get_max_vorticity()))
+    d_gpu, d_cpu = gpu.get_vorticity_divergence_l2_norm(), cpu.get_vorticity_divergence_l2_norm()
+    assert abs(d_gpu - d_cpu) <= 1e-4 * max(d_cpu, 1e-12)
+
+
+def test_simulator_known_answers(smi):
+    """The reference's own closed-form checks (tests/test_simulator/test_flow/
+    test_flow_simulators_3d.py:333-360, 441-500) run against the GPU simulator."""
+    from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
+    from sopht_mpi_amd.sopht_compat import get_test_tol
+
+    for precision, real_t in (("single", np.float32), ("double", np.float64)):
+        n, cfl, nu = 8, 0.2, 1.0
+        dx = real_t(1.0 / n)
+        sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, CFL=cfl, kinematic_viscosity=nu,
+                                       real_t=real_t)
+        sim.velocity_field[...] = 2.0
+        got = sim.compute_stable_timestep(dt_prefac=0.5, precision=precision)
+        adv = cfl * dx / (3 * 2.0 + get_test_tol(precision))
+        dif = 0.9 * dx**2 / 6 / (nu + get_test_tol(precision))
+        assert got == 0.5 * min(adv, dif)
+        sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=1e-2, real_t=real_t,
+                                       flow_type="navier_stokes_with_forcing")
+        w = np.random.default_rng(0).random(sim.vorticity_field.shape).astype(real_t)
+        w[0, 6, 6, 6] = 10.0
+        sim.vorticity_field[...] = w
+        assert sim.get_max_vorticity() == 10.0
+
+
+def test_invalid_arguments(smi):
+    from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
+
+    with pytest.raises(ValueError):
+        UnboundedFlowSimulator3D(grid_size=(8, 8, 8), x_range=1.0, kinematic_viscosity=1.0, flow_type="bogus")
+    with pytest.raises(ValueError):  # ghost size smaller than the ENO3 support
+        UnboundedFlowSimulator3D(grid_size=(8, 8, 8), x_range=1.0, kinematic_viscosity=1.0, ghost_size=1)

@@ -1,0 +1,101 @@
+"""GPU parity: unbounded Poisson solve against the oracle (scipy.fft restatement of
+UnboundedPoissonSolverMPI3D), both back ends, plus size-independent properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import assert_close, make_ctx, rand_field
+from oracle.poisson import UnboundedPoissonSolver3D
+
+pytestmark = pytest.mark.gpu
+
+BACKENDS = ["rocfft", "pruned"]
+
+
+def _solver(smi, ctx, shape, x_range, real_t, backend):
+    from sopht_mpi_amd._lib import SophtMIError, call
+
+    h = C.c_void_p()
+    code = {"rocfft": 0, "pruned": 1}[backend]
+    dx = real_t(x_range / shape[2])
+    try:
+        call("smi_poisson_create", C.byref(h), ctx.handle, shape[0], shape[1], shape[2], float(dx), float(x_range),
+             code)
+    except SophtMIError as exc:
+        if "power of two" in str(exc) or "not available" in str(exc):
+            pytest.skip(str(exc))
+        raise
+    return h
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,g", [((8, 8, 8), 2), ((16, 16, 16), 2), ((8, 16, 32), 1), ((32, 32, 32), 2),
+                                     ((8, 12, 16), 2)])
+def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
+    rng = np.random.default_rng(7)
+    ctx = make_ctx(smi, shape, g, real_t)
+    x_range = 1.3
+    h = _solver(smi, ctx, shape, x_range, real_t, backend)
+    rhs = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    sol0 = rand_field(rng, (3,) + ctx.padded_shape, real_t)  # ghosts of the solution must be left alone
+    drhs, dsol = ctx.from_numpy(rhs), ctx.from_numpy(sol0)
+    smi._lib.call("smi_poisson_vector_solve", h, dsol.ptr, drhs.ptr)
+    oracle = UnboundedPoissonSolver3D(*shape, x_range=x_range, real_t=real_t)
+    want = sol0.copy()
+    oracle.vector_field_solve(want, rhs, g)
+    got = dsol.get()
+    inner = (slice(None),) + (slice(g, -g),) * 3
+    assert_close(got[inner], want[inner], real_t, factor=2.0, what=f"poisson[{backend}]")
+    mask = np.ones(got.shape, dtype=bool)
+    mask[inner] = False
+    assert np.array_equal(got[mask], sol0[mask]), "solution ghost cells were modified"
+    assert np.array_equal(drhs.get(), rhs), "rhs was modified"
+    # scalar entry point, third component
+    dsol1 = ctx.field()
+    smi._lib.call("smi_poisson_solve", h, dsol1.ptr, drhs[2].ptr)
+    assert_close(dsol1.get()[inner[1:]], want[2][inner[1:]], real_t, factor=2.0, what="scalar solve")
+    smi._lib.call("smi_poisson_destroy", h)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_poisson_linearity_and_point_source(smi, backend):
+    """Size-independent properties: linearity, and the response to a unit point source is the
+    regularised Green's function (1 / (4 pi r), value 1 / (4 pi dx) at r = 0) times dx^3."""
+    real_t, shape, g = np.float32, (32, 32, 32), 2
+    rng = np.random.default_rng(8)
+    ctx = make_ctx(smi, shape, g, real_t)
+    h = _solver(smi, ctx, shape, 1.0, real_t, backend)
+    dx = real_t(1.0 / 32)
+    a = rand_field(rng, ctx.padded_shape, real_t)
+    b = rand_field(rng, ctx.padded_shape, real_t)
+    da, db, dab = ctx.from_numpy(a), ctx.from_numpy(b), ctx.from_numpy(a + real_t(2) * b)
+    sa, sb, sab = ctx.field(), ctx.field(), ctx.field()
+    for s, r in ((sa, da), (sb, db), (sab, dab)):
+        smi._lib.call("smi_poisson_solve", h, s.ptr, r.ptr)
+    assert_close(sab.get(), sa.get() + real_t(2) * sb.get(), real_t, factor=4.0, what="linearity")
+    src = np.zeros(ctx.padded_shape, dtype=real_t)
+    src[g + 5, g + 7, g + 9] = 1.0
+    dsrc, ds = ctx.from_numpy(src), ctx.field()
+    smi._lib.call("smi_poisson_solve", h, ds.ptr, dsrc.ptr)
+    got = ds.get()[g:-g, g:-g, g:-g]
+    z, y, x = np.meshgrid(*(np.arange(32),) * 3, indexing="ij")
+    r = np.sqrt((z - 5.0) ** 2 + (y - 7.0) ** 2 + (x - 9.0) ** 2) * float(dx)
+    with np.errstate(divide="ignore"):
+        want = 1.0 / (4 * np.pi * r)
+    want[5, 7, 9] = 1.0 / (4 * np.pi * float(dx))
+    want *= float(dx) ** 3
+    assert_close(got, want, real_t, factor=5.0, what="point source")
+    smi._lib.call("smi_poisson_destroy", h)
+
+
+def test_poisson_rejects_bad_arguments(smi):
+    from sopht_mpi_amd._lib import SophtMIError, call
+
+    ctx = make_ctx(smi, (8, 8, 8), 2, np.float32)
+    h = C.c_void_p()
+    with pytest.raises(SophtMIError):
+        call("smi_poisson_create", C.byref(h), ctx.handle, 8, 8, 16, 0.125, 1.0, 0)  # grid mismatch
+    with pytest.raises(SophtMIError):
+        call("smi_poisson_create", C.byref(h), ctx.handle, 8, 8, 8, 0.125, 1.0, 5)  # bad back end

@@ -1,0 +1,187 @@
+"""GPU parity: every 3D stencil / elementwise operator of libsophtmi against the oracle on
+the same seeded ghosted arrays (whole array compared, ghost cells included)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import assert_close, make_ctx, rand_field
+from oracle import stencils_3d as st
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (nz, ny, nx), ghost
+    ((8, 8, 8), 2),
+    ((8, 12, 16), 2),   # aspect ratio (1, 1.5, 2) of the reference tests
+    ((8, 8, 8), 1),
+    ((10, 9, 11), 2),   # px not a multiple of 4: scalar path
+    ((12, 20, 36), 3),
+]
+
+
+def _call(smi, name, *a):
+    smi._lib.call(name, *a)
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,g", CASES)
+def test_elementwise_ops(smi, shape, g, real_t):
+    rng = np.random.default_rng(1)
+    ctx = make_ctx(smi, shape, g, real_t)
+    pshape = ctx.padded_shape
+    a = rand_field(rng, (3,) + pshape, real_t)
+    b = rand_field(rng, (3,) + pshape, real_t)
+    da, db, dr = ctx.from_numpy(a), ctx.from_numpy(b), ctx.field(3)
+    _call(smi, "smi_cross_product", ctx.handle, dr.ptr, da.ptr, db.ptr)
+    want = np.zeros_like(a)
+    st.elementwise_cross_product(want, a, b)
+    assert_close(dr.get(), want, real_t, what="cross")
+    _call(smi, "smi_elementwise_sum", ctx.handle, dr.ptr, da.ptr, db.ptr, 3)
+    assert_close(dr.get(), a + b, real_t, what="sum")
+    _call(smi, "smi_elementwise_saxpby", ctx.handle, dr.ptr, da.ptr, 1.0, db.ptr, -1.0, 3)
+    assert_close(dr.get(), a - b, real_t, what="saxpby")
+    _call(smi, "smi_elementwise_copy", ctx.handle, dr.ptr, da.ptr, 3)
+    assert np.array_equal(dr.get(), a)
+    vals = smi._lib.darray([1.0, -2.0, 0.5])
+    _call(smi, "smi_add_fixed_val", ctx.handle, dr.ptr, da.ptr, 3, vals)
+    assert_close(dr.get(), a + np.array([1.0, -2.0, 0.5], dtype=real_t).reshape(3, 1, 1, 1), real_t, what="add")
+    _call(smi, "smi_set_fixed_val", ctx.handle, dr.ptr, 3, vals)
+    assert np.array_equal(dr.get(), np.broadcast_to(np.array([1.0, -2.0, 0.5], dtype=real_t).reshape(3, 1, 1, 1),
+                                                    a.shape))
+    # a component view (odd alignment on some shapes) must work as well
+    _call(smi, "smi_elementwise_sum", ctx.handle, dr[1].ptr, da[1].ptr, db[2].ptr, 1)
+    assert_close(dr[1].get(), a[1] + b[2], real_t, what="component sum")
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,g", CASES)
+def test_diffusion_flux_and_timestep(smi, shape, g, real_t):
+    rng = np.random.default_rng(2)
+    ctx = make_ctx(smi, shape, g, real_t)
+    f = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    c = real_t(0.137)
+    # flux: stale garbage in the output must not survive
+    dflux = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    df = ctx.from_numpy(f)
+    _call(smi, "smi_diffusion_flux", ctx.handle, dflux.ptr, df.ptr, float(c), 3)
+    want = np.zeros_like(f)
+    for k in range(3):
+        st.diffusion_flux(want[k], f[k], c, g)
+    assert_close(dflux.get(), want, real_t, what="diffusion flux")
+    # timestep with one scalar scratch
+    dscr = ctx.field()
+    _call(smi, "smi_diffusion_timestep", ctx.handle, df.ptr, dscr.ptr, float(c), 3)
+    wf, wscr = f.copy(), np.zeros(ctx.padded_shape, dtype=real_t)
+    st.vector_diffusion_timestep(wf, wscr, c, g)
+    assert_close(df.get(), wf, real_t, what="diffusion timestep")
+    assert_close(dscr.get(), wscr, real_t, scale=np.abs(wf).max(), what="flux scratch")
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,g", CASES)
+def test_curl_update_divergence(smi, shape, g, real_t):
+    rng = np.random.default_rng(3)
+    ctx = make_ctx(smi, shape, g, real_t)
+    f = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    w = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    p = real_t(0.73)
+    df, dw = ctx.from_numpy(f), ctx.from_numpy(w)
+    _call(smi, "smi_update_vorticity_from_velocity_forcing", ctx.handle, dw.ptr, df.ptr, float(p))
+    want = w.copy()
+    st.update_vorticity_from_velocity_forcing(want, f, p, g)
+    assert_close(dw.get(), want, real_t, what="update vorticity")
+    # cells outside the reference's seven boxes must be bit-identical to the input
+    untouched = want == w
+    assert np.array_equal(dw.get()[untouched], w[untouched])
+
+    dc = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    _call(smi, "smi_curl", ctx.handle, dc.ptr, df.ptr, float(p))
+    wc = np.zeros_like(f)
+    st.curl(wc, f, p, g)
+    assert_close(dc.get(), wc, real_t, what="curl")
+
+    dd = ctx.from_numpy(rand_field(rng, ctx.padded_shape, real_t))
+    inv_dx = real_t(8.0)
+    _call(smi, "smi_divergence", ctx.handle, dd.ptr, df.ptr, float(inv_dx))
+    wd = np.zeros(ctx.padded_shape, dtype=real_t)
+    st.divergence(wd, f, inv_dx, g)
+    assert_close(dd.get(), wd, real_t, what="divergence")
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("width", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape,g", [((12, 12, 12), 2), ((12, 14, 16), 1), ((16, 12, 20), 2)])
+def test_penalise_boundary(smi, shape, g, width, real_t):
+    from oracle.flow_3d import local_coordinates
+    from sopht_mpi_amd.numeric.eulerian_grid_ops import penalty_factor_tables
+
+    rng = np.random.default_rng(4)
+    ctx = make_ctx(smi, shape, g, real_t)
+    dx = real_t(1.0 / shape[2])
+    zc, yc, xc = (local_coordinates(n, 0, dx, g, real_t) for n in shape)
+    f = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    df = ctx.from_numpy(f)
+    if width == 0:
+        _call(smi, "smi_penalise_boundary", ctx.handle, df.ptr, 3, 0, None, None)
+        assert np.array_equal(df.get(), f)
+        return
+    pos = np.flipud(np.array(np.meshgrid(zc, yc, xc, indexing="ij")))
+    lo, hi = penalty_factor_tables(width, dx, pos[0], pos[1], pos[2], g, real_t)
+    _call(smi, "smi_penalise_boundary", ctx.handle, df.ptr, 3, width, smi._lib.darray(lo), smi._lib.darray(hi))
+    want = f.copy()
+    st.penalise_vector_field_boundary(want, width, dx, xc, yc, zc, g)
+    assert_close(df.get(), want, real_t, what="penalise")
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("filter_type", ["multiplicative", "convolution"])
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("shape,g", [((8, 8, 8), 2), ((8, 12, 16), 1)])
+def test_laplacian_filter(smi, shape, g, order, filter_type, real_t):
+    rng = np.random.default_rng(5)
+    ctx = make_ctx(smi, shape, g, real_t)
+    f = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    df = ctx.from_numpy(f)
+    dflux = ctx.from_numpy(rand_field(rng, ctx.padded_shape, real_t))
+    dbuf = ctx.from_numpy(rand_field(rng, ctx.padded_shape, real_t))
+    code = {"multiplicative": 0, "convolution": 1}[filter_type]
+    _call(smi, "smi_laplacian_filter", ctx.handle, df.ptr, 3, dflux.ptr, dbuf.ptr, order, code)
+    want = f.copy()
+    st.vector_laplacian_filter(want, np.zeros(ctx.padded_shape, real_t), np.zeros(ctx.padded_shape, real_t), order, g,
+                               filter_type)
+    assert_close(df.get(), want, real_t, what="filter")
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+def test_reductions(smi, real_t):
+    rng = np.random.default_rng(6)
+    shape, g = (8, 12, 16), 2
+    ctx = make_ctx(smi, shape, g, real_t)
+    u = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    u[:, 0, 0, 0] = 100.0  # ghost cells must not count
+    du = ctx.from_numpy(u)
+    inner = (slice(None),) + (slice(g, -g),) * 3
+    out = C.c_double()
+    _call(smi, "smi_reduce_max_abs_sum", ctx.handle, du.ptr, C.byref(out))
+    assert real_t(out.value) == np.amax(np.sum(np.fabs(u), axis=0)[inner[1:]])
+    _call(smi, "smi_reduce_max", ctx.handle, du.ptr, 3, C.byref(out))
+    assert real_t(out.value) == np.amax(u[inner])
+    _call(smi, "smi_reduce_sum_sq", ctx.handle, du[0].ptr, 1, C.byref(out))
+    want = np.sum(u[0][inner[1:]].astype(np.float64) ** 2)
+    assert abs(out.value - want) <= 1e-12 * want
+
+
+def test_argument_errors(smi):
+    """Error behaviour of the boundary: bad arguments come back as exceptions, not faults."""
+    from sopht_mpi_amd._lib import SophtMIError
+    from sopht_mpi_amd.device import DeviceContext
+
+    with pytest.raises(SophtMIError):
+        DeviceContext((8, 8, 8), 0, np.float32)
+    ctx = make_ctx(smi, (8, 8, 8), 2, np.float32)
+    f = ctx.field(3)
+    with pytest.raises(SophtMIError):
+        smi._lib.call("smi_curl", ctx.handle, f.ptr, f.ptr, 1.0)  # aliasing
+    with pytest.raises(SophtMIError):
+        smi._lib.call("smi_laplacian_filter", ctx.handle, f.ptr, 3, f[0].ptr, f[1].ptr, 1, 7)
