@@ -67,6 +67,11 @@ int smi_comm_init(smi_ctx* ctx, const void* unique_id128);
  * Replaces nothing in the reference (its transport is always MPI). */
 typedef int (*smi_exchange_cb)(void* user, void* field, int ncomp, int kind);
 int smi_set_exchange_callback(smi_ctx* ctx, smi_exchange_cb cb, void* user);
+/* Same hook for the FFT transposes: block r (bytes_per_peer bytes) of the device buffer
+ * `send` goes to rank r, block s of `recv` comes from rank s.  `user` is the pointer given
+ * to smi_set_exchange_callback. */
+typedef int (*smi_alltoall_cb)(void* user, const void* send, void* recv, size_t bytes_per_peer);
+int smi_set_alltoall_callback(smi_ctx* ctx, smi_alltoall_cb cb);
 /* allreduce of n host doubles over the slab ranks through RCCL; op: 0 = sum, 1 = min,
  * 2 = max.  Replaces grid.allreduce (flow_simulators_mpi_3d.py:448, 465-467, 475). */
 int smi_allreduce_f64(smi_ctx* ctx, double* host_inout, int n, int op);

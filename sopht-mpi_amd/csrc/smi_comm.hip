@@ -77,6 +77,37 @@ int smi_halo_exchange_impl(smi_ctx* c, void* field, int ncomp) {
   return 0;
 }
 
+// All-to-all of equal contiguous blocks: block r of `send` goes to rank r, block s of `recv`
+// comes from rank s.  Replaces the Alltoallw transposes inside mpi4py-fft's PFFT
+// (fft_mpi_3d.py:27-48).  One RCCL group of point-to-point pairs: on xGMI every pair has its
+// own link, so all seven peers move at once.
+int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer) {
+  if (c->nranks == 1) {
+    if (send != recv) SMI_CHECK_HIP(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+  }
+  if (c->alltoall_cb) {
+    int rc = c->alltoall_cb(c->exchange_user, send, recv, bytes_per_peer);
+    SMI_REQUIRE(rc == 0, "all-to-all callback failed (%d)", rc);
+    return 0;
+  }
+  SMI_REQUIRE(c->comm_ready, "all-to-all across ranks needs smi_comm_init or a transport callback");
+  SMI_CHECK_NCCL(ncclGroupStart());
+  for (int r = 0; r < c->nranks; ++r) {
+    SMI_CHECK_NCCL(ncclSend((const char*)send + (size_t)r * bytes_per_peer, bytes_per_peer, ncclChar, r, c->comm,
+                            c->stream));
+    SMI_CHECK_NCCL(ncclRecv((char*)recv + (size_t)r * bytes_per_peer, bytes_per_peer, ncclChar, r, c->comm, c->stream));
+  }
+  SMI_CHECK_NCCL(ncclGroupEnd());
+  return 0;
+}
+
+extern "C" int smi_set_alltoall_callback(smi_ctx* c, smi_alltoall_cb cb) {
+  SMI_REQUIRE(c, "smi_set_alltoall_callback: null context");
+  c->alltoall_cb = cb;
+  return 0;
+}
+
 extern "C" int smi_halo_exchange(smi_ctx* c, void* field, int ncomp) {
   SMI_REQUIRE(c && field && ncomp >= 1, "smi_halo_exchange: bad argument");
   return smi_halo_exchange_impl(c, field, ncomp);

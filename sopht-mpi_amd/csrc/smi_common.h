@@ -32,6 +32,7 @@ struct smi_ctx {
   size_t halo_cap;     // bytes per staging buffer
   void* fac_dev;       // small device scratch (allreduce staging)
   smi_exchange_cb exchange_cb;
+  smi_alltoall_cb alltoall_cb;
   SmiProf* prof;
   void* exchange_user;
 };
