@@ -170,13 +170,14 @@ __device__ __forceinline__ void butterflies(Cx<T> (&v)[8], int (&pos)[8], int u,
   }
 }
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;      // pointwise helper kernels
+constexpr int kMaxThreads = 1024;  // FFT kernels: one work item per thread, TS * L / 8 threads
 
-// Work item i of this thread: sequence t (fastest over lanes) and element group u.
+// The work item of this thread: sequence t (fastest over lanes) and element group u.
 struct Items {
   int ts_mask, ts_shift;
-  __device__ __forceinline__ int t(int i) const { return (threadIdx.x + i * kThreads) & ts_mask; }
-  __device__ __forceinline__ int u(int i) const { return (threadIdx.x + i * kThreads) >> ts_shift; }
+  __device__ __forceinline__ int t(int) const { return threadIdx.x & ts_mask; }
+  __device__ __forceinline__ int u(int) const { return threadIdx.x >> ts_shift; }
 };
 
 // All stages of one batched FFT.  LDS tile layout: lds[pos * TSP + t].
@@ -226,7 +227,7 @@ struct PGeo {
 
 // ------------------------------------------------------------------------- y forward
 template <typename T, int BPT>
-__global__ void __launch_bounds__(kThreads) k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out,
+__global__ void __launch_bounds__(kMaxThreads) k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out,
                                                         PGeo G, FftPlan P, const Cx<T>* __restrict__ tw4, int ts_shift) {
   extern __shared__ char smem[];
   Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
@@ -235,20 +236,22 @@ __global__ void __launch_bounds__(kThreads) k_fft_y_fwd(const Cx<T>* __restrict_
   const int c = blockIdx.z, z = blockIdx.y, kx0 = blockIdx.x * TS;
   const Cx<T>* src = in + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP;
   Cx<T>* dst = out + (((size_t)c * G.nz + z) * (2 * G.ny)) * (size_t)G.KXP;
-  Cx<T> v[BPT][8];
+  Cx<T> v[BPT][8], a0[BPT][8];
   int pos[BPT][8];
+  // the column is read once and kept in registers for both parities
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int col = kx0 + it.t(i), u = it.u(i);
+    const bool ok = col < G.KXL;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) a0[i][m] = ok ? src[(size_t)(u + m * P.L8) * G.KXP + col] : Cx<T>{0, 0};
+  }
   for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
-      const int col = kx0 + it.t(i), u = it.u(i);
-      const bool ok = col < G.KXL;
+      const int u = it.u(i);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int n = u + m * P.L8;
-        Cx<T> a = ok ? src[(size_t)n * G.KXP + col] : Cx<T>{0, 0};
-        if (parity) a = a * tw4[2 * n];
-        v[i][m] = a;
-      }
+      for (int m = 0; m < 8; ++m) v[i][m] = parity ? a0[i][m] * tw4[2 * (u + m * P.L8)] : a0[i][m];
     }
     fft_run<-1, false, BPT>(v, pos, P, lds, TS, it, tw4);
 #pragma unroll
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(kThreads) k_fft_y_fwd(const Cx<T>* __restrict_
 
 // ------------------------------------------------------------------------- y inverse
 template <typename T, int BPT>
-__global__ void __launch_bounds__(kThreads) k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out,
+__global__ void __launch_bounds__(kMaxThreads) k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out,
                                                         PGeo G, FftPlan P, const Cx<T>* __restrict__ tw4, int ts_shift) {
   extern __shared__ char smem[];
   Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(kThreads) k_fft_y_inv(const Cx<T>* __restrict_
 // ------------------------------------------------------------------------- z convolution
 // forward nz -> 2nz, multiply by the folded Green's table, inverse 2nz -> nz, in place.
 template <typename T, int BPT>
-__global__ void __launch_bounds__(kThreads) k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G,
+__global__ void __launch_bounds__(kMaxThreads) k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G,
                                                          FftPlan P, const Cx<T>* __restrict__ tw4, int ts_shift) {
   extern __shared__ char smem[];
   Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
@@ -322,20 +325,22 @@ __global__ void __launch_bounds__(kThreads) k_fft_z_conv(Cx<T>* __restrict__ buf
   const int kyc = ky <= G.ny ? ky : 2 * G.ny - ky;
   const T* gbase = green + (size_t)kyc * G.KXP;
   const size_t gstride = (size_t)(G.ny + 1) * G.KXP;
-  Cx<T> v[BPT][8], res[BPT][8];
+  Cx<T> v[BPT][8], res[BPT][8], a0[BPT][8];
   int pos[BPT][8];
+  // the column is read once and kept in registers for both parities
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int col = kx0 + it.t(i), u = it.u(i);
+    const bool ok = col < G.KXL;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) a0[i][m] = ok ? base[(size_t)(u + m * P.L8) * zstride + col] : Cx<T>{0, 0};
+  }
   for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
-      const int col = kx0 + it.t(i), u = it.u(i);
-      const bool ok = col < G.KXL;
+      const int u = it.u(i);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int n = u + m * P.L8;
-        Cx<T> a = ok ? base[(size_t)n * zstride + col] : Cx<T>{0, 0};
-        if (pz) a = a * tw4[2 * n];
-        v[i][m] = a;
-      }
+      for (int m = 0; m < 8; ++m) v[i][m] = pz ? a0[i][m] * tw4[2 * (u + m * P.L8)] : a0[i][m];
     }
     fft_run<-1, false, BPT>(v, pos, P, lds, TS, it, tw4);
     // spectrum at kz = 2 pos + pz, times the Green's table; into the tile in natural order
@@ -386,7 +391,7 @@ struct FieldGeo {
 };
 
 template <typename T, int BPT>
-__global__ void __launch_bounds__(kThreads) k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G,
+__global__ void __launch_bounds__(kMaxThreads) k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G,
                                                         FieldGeo F, FftPlan P, const Cx<T>* __restrict__ tw4,
                                                         int ts_shift) {
   extern __shared__ char smem[];
@@ -394,13 +399,13 @@ __global__ void __launch_bounds__(kThreads) k_fft_x_fwd(const T* __restrict__ fi
   const int TS = 1 << ts_shift, TSP = TS + 1;
   const Items it{TS - 1, ts_shift};
   const int c = blockIdx.z, zl = blockIdx.y, y0 = blockIdx.x * TS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int L = P.L;
   const T* fbase = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + F.g;
   Cx<T> v[BPT][8];
   int pos[BPT][8];
   for (int parity = 0; parity < 2; ++parity) {
-    for (int r = wave; r < TS; r += kThreads / 64) {
+    for (int r = wave; r < TS; r += nwaves) {
       const int y = y0 + r;
       const T* row = fbase + (size_t)(y + F.g) * F.px;
       for (int n = lane; n < L; n += 64) {
@@ -422,7 +427,7 @@ __global__ void __launch_bounds__(kThreads) k_fft_x_fwd(const T* __restrict__ fi
     }
     __syncthreads();
     const int cnt = L + 1 - parity;
-    for (int r = wave; r < TS; r += kThreads / 64) {
+    for (int r = wave; r < TS; r += nwaves) {
       const int y = y0 + r;
       if (y >= G.ny) continue;
       for (int m = lane; m < cnt; m += 64) {
@@ -449,7 +454,7 @@ __global__ void __launch_bounds__(kThreads) k_fft_x_fwd(const T* __restrict__ fi
 
 // ------------------------------------------------------------------------- x inverse
 template <typename T, int BPT>
-__global__ void __launch_bounds__(kThreads) k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G,
+__global__ void __launch_bounds__(kMaxThreads) k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G,
                                                         FieldGeo F, FftPlan P, const Cx<T>* __restrict__ tw4,
                                                         int ts_shift) {
   extern __shared__ char smem[];
@@ -457,14 +462,14 @@ __global__ void __launch_bounds__(kThreads) k_fft_x_inv(const Cx<T>* __restrict_
   const int TS = 1 << ts_shift, TSP = TS + 1;
   const Items it{TS - 1, ts_shift};
   const int c = blockIdx.z, zl = blockIdx.y, y0 = blockIdx.x * TS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int L = P.L;
   T* fbase = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + F.g;
   Cx<T> v[BPT][8], res[BPT][8];
   int pos[BPT][8];
   for (int parity = 0; parity < 2; ++parity) {
     const int cnt = L + 1 - parity;
-    for (int r = wave; r < TS; r += kThreads / 64) {
+    for (int r = wave; r < TS; r += nwaves) {
       const int y = y0 + r;
       for (int m = lane; m < cnt; m += 64) {
         Cx<T> a{0, 0};
@@ -480,7 +485,7 @@ __global__ void __launch_bounds__(kThreads) k_fft_x_inv(const Cx<T>* __restrict_
     // Z[k] = E[k] + i O[k], E = (X[k] + conj X[M-k]) / 2, O = (X[k] - conj X[M-k]) / 2 * e^{+2 pi i k / 2M};
     // pairs (k, M-k) share their two inputs, so each lane rewrites one pair in place.
     const int npair = parity ? L / 2 : L / 2 + 1;
-    for (int r = wave; r < TS; r += kThreads / 64) {
+    for (int r = wave; r < TS; r += nwaves) {
       for (int m = lane; m < npair; m += 64) {
         const int m2 = parity ? L - 1 - m : L - m;  // partner index in this parity block
         Cx<T> xa = lds[m * TSP + r], xb = lds[m2 * TSP + r];
@@ -512,7 +517,7 @@ __global__ void __launch_bounds__(kThreads) k_fft_x_inv(const Cx<T>* __restrict_
         }
       }
       __syncthreads();
-      for (int r = wave; r < TS; r += kThreads / 64) {
+      for (int r = wave; r < TS; r += nwaves) {
         const int y = y0 + r;
         if (y >= G.ny) continue;
         T* row = fbase + (size_t)(y + F.g) * F.px;
@@ -548,15 +553,14 @@ __global__ void __launch_bounds__(kThreads) k_fold_green(T* __restrict__ green, 
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-int choose_bpt(int L, bool f32, bool rows) {
-  // columns want >= 16 (f32) / 8 (f64) sequences per tile so that every row of the tile is a
-  // full 128-byte line; the tile is 2048 * BPT points.
+// Sequences per tile.  Columns want >= 16 (f32) / 8 (f64) so that every row of the tile is
+// a whole 128-byte line; one work item (8 points) per thread, 256..1024 threads.
+int choose_ts(int L, bool f32, bool rows) {
   int want = rows ? 4 : (f32 ? 16 : 8);
-  int bpt = want * L / 2048;
-  int cap = f32 ? 4 : 2;
-  if (bpt < 1) bpt = 1;
-  if (bpt > cap) bpt = cap;
-  return bpt;
+  int ts = 2048 / L > want ? 2048 / L : want;
+  if (ts * L / 8 > kMaxThreads) ts = kMaxThreads * 8 / L;
+  if (ts < 1) ts = 1;
+  return ts;
 }
 
 int ilog2(int n) {
@@ -574,7 +578,7 @@ int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per
 struct PrunedState {
   PGeo G;
   FftPlan px, py, pz;
-  int bpt_x, bpt_y, bpt_z;
+  int ts_x, ts_y, ts_z;
   void* tw[3] = {nullptr, nullptr, nullptr};  // x, y, z twiddle tables (4L complex each)
   void* bufA = nullptr;
   void* bufT = nullptr;  // == bufA on a single rank
@@ -636,9 +640,9 @@ int smi_pruned_create(smi_poisson* p) {
   s->py = make_plan(G.ny);
   s->pz = make_plan(G.nz);
   const bool f32 = c->dtype == SMI_F32;
-  s->bpt_x = choose_bpt(s->px.L, f32, true);
-  s->bpt_y = choose_bpt(s->py.L, f32, false);
-  s->bpt_z = choose_bpt(s->pz.L, f32, false);
+  s->ts_x = choose_ts(s->px.L, f32, true);
+  s->ts_y = choose_ts(s->py.L, f32, false);
+  s->ts_z = choose_ts(s->pz.L, f32, false);
   const size_t cs = 2 * smi_elem_size(c);
   const size_t nA = (size_t)G.P * G.nc * G.nzl * G.ny * G.KXP;
   const size_t nB = (size_t)G.nc * G.nz * 2 * G.ny * G.KXP;
@@ -687,24 +691,24 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int nc) {
   PGeo G = s->G;
   G.nc = nc;
   const FftPlan& P = which == 1 ? s->pz : s->py;
-  const int TS = 2048 * BPT / P.L, ts_shift = ilog2(TS);
+  const int TS = which == 1 ? s->ts_z : s->ts_y, ts_shift = ilog2(TS), nthreads = TS * P.L / 8;
   const size_t lds_bytes = (size_t)P.L * TS * sizeof(Cx<T>);
   dim3 grid((G.KXL + TS - 1) / TS, which == 1 ? 2 * G.ny : G.nz, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[which == 1 ? 2 : 1];
   if (which == 0) {
     SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_y_fwd<T, BPT>, lds_bytes)));
     SmiProfScope prof(c, PROF_FFT_Y_FWD, 6.0 * nc * smi_S(c));
-    k_fft_y_fwd<T, BPT><<<grid, kThreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, P, tw,
+    k_fft_y_fwd<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, P, tw,
                                                                  ts_shift);
   } else if (which == 1) {
     SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_z_conv<T, BPT>, lds_bytes)));
     SmiProfScope prof(c, PROF_FFT_Z_CONV, 9.0 * nc * smi_S(c));
-    k_fft_z_conv<T, BPT><<<grid, kThreads, lds_bytes, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G, P, tw,
+    k_fft_z_conv<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G, P, tw,
                                                                   ts_shift);
   } else {
     SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_y_inv<T, BPT>, lds_bytes)));
     SmiProfScope prof(c, PROF_FFT_Y_INV, 6.0 * nc * smi_S(c));
-    k_fft_y_inv<T, BPT><<<grid, kThreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, P, tw,
+    k_fft_y_inv<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, P, tw,
                                                                  ts_shift);
   }
   SMI_LAUNCH_CHECK();
@@ -716,7 +720,7 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int nc, void* field
   PGeo G = s->G;
   G.nc = nc;
   const FftPlan& P = s->px;
-  const int TS = 2048 * BPT / P.L, ts_shift = ilog2(TS);
+  const int TS = s->ts_x, ts_shift = ilog2(TS), nthreads = TS * P.L / 8;
   const size_t lds_bytes = (size_t)(P.L + 1) * (TS + 1) * sizeof(Cx<T>);
   FieldGeo F{c->g, c->px, (long long)c->plane, (long long)c->vol};
   dim3 grid((G.ny + TS - 1) / TS, G.nzl, nc);
@@ -724,12 +728,12 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int nc, void* field
   if (fwd) {
     SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_x_fwd<T, BPT>, lds_bytes)));
     SmiProfScope prof(c, PROF_FFT_X_FWD, 3.0 * nc * smi_S(c));
-    k_fft_x_fwd<T, BPT><<<grid, kThreads, lds_bytes, c->stream>>>((const T*)field, (Cx<T>*)s->bufA, G, F, P, tw,
+    k_fft_x_fwd<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const T*)field, (Cx<T>*)s->bufA, G, F, P, tw,
                                                                  ts_shift);
   } else {
     SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_x_inv<T, BPT>, lds_bytes)));
     SmiProfScope prof(c, PROF_FFT_X_INV, 3.0 * nc * smi_S(c));
-    k_fft_x_inv<T, BPT><<<grid, kThreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufA, (T*)field, G, F, P, tw,
+    k_fft_x_inv<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufA, (T*)field, G, F, P, tw,
                                                                  ts_shift);
   }
   SMI_LAUNCH_CHECK();
@@ -739,8 +743,7 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int nc, void* field
 #define BPT_SWITCH(bpt, ...)            \
   switch (bpt) {                        \
     case 1: { constexpr int BPT = 1; __VA_ARGS__ } break; \
-    case 2: { constexpr int BPT = 2; __VA_ARGS__ } break; \
-    default: { constexpr int BPT = 4; __VA_ARGS__ } break; \
+    default: { constexpr int BPT = 1; __VA_ARGS__ } break; \
   }
 
 int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp) {
@@ -752,19 +755,19 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
   const size_t cs = 2 * smi_elem_size(c);
   const size_t peer_bytes = (size_t)ncomp * G.nzl * G.ny * G.KXP * cs;
   SMI_DISPATCH(c, {
-    BPT_SWITCH(s->bpt_x, SMI_CHECK((launch_rows<T, BPT>(c, s, true, ncomp, (void*)rhs)));)
+    BPT_SWITCH(1, SMI_CHECK((launch_rows<T, BPT>(c, s, true, ncomp, (void*)rhs)));)
     if (G.P > 1) {
       SmiProfScope prof(c, PROF_TRANSPOSE, (double)peer_bytes * G.P);
       SMI_CHECK(smi_alltoall_impl(c, s->bufA, s->bufT, peer_bytes));
     }
-    BPT_SWITCH(s->bpt_y, SMI_CHECK((launch_cols<T, BPT>(c, s, 0, ncomp)));)
-    BPT_SWITCH(s->bpt_z, SMI_CHECK((launch_cols<T, BPT>(c, s, 1, ncomp)));)
-    BPT_SWITCH(s->bpt_y, SMI_CHECK((launch_cols<T, BPT>(c, s, 2, ncomp)));)
+    BPT_SWITCH(1, SMI_CHECK((launch_cols<T, BPT>(c, s, 0, ncomp)));)
+    BPT_SWITCH(1, SMI_CHECK((launch_cols<T, BPT>(c, s, 1, ncomp)));)
+    BPT_SWITCH(1, SMI_CHECK((launch_cols<T, BPT>(c, s, 2, ncomp)));)
     if (G.P > 1) {
       SmiProfScope prof(c, PROF_TRANSPOSE, (double)peer_bytes * G.P);
       SMI_CHECK(smi_alltoall_impl(c, s->bufT, s->bufA, peer_bytes));
     }
-    BPT_SWITCH(s->bpt_x, SMI_CHECK((launch_rows<T, BPT>(c, s, false, ncomp, solution)));)
+    BPT_SWITCH(1, SMI_CHECK((launch_rows<T, BPT>(c, s, false, ncomp, solution)));)
   });
   return 0;
 }
