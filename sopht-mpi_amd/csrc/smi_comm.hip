@@ -92,8 +92,13 @@ int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per
     return 0;
   }
   SMI_REQUIRE(c->comm_ready, "all-to-all across ranks needs smi_comm_init or a transport callback");
+  // own block: a plain device copy, stream-ordered with the group
+  SMI_CHECK_HIP(hipMemcpyAsync((char*)recv + (size_t)c->rank * bytes_per_peer,
+                               (const char*)send + (size_t)c->rank * bytes_per_peer, bytes_per_peer,
+                               hipMemcpyDeviceToDevice, c->stream));
   SMI_CHECK_NCCL(ncclGroupStart());
   for (int r = 0; r < c->nranks; ++r) {
+    if (r == c->rank) continue;
     SMI_CHECK_NCCL(ncclSend((const char*)send + (size_t)r * bytes_per_peer, bytes_per_peer, ncclChar, r, c->comm,
                             c->stream));
     SMI_CHECK_NCCL(ncclRecv((char*)recv + (size_t)r * bytes_per_peer, bytes_per_peer, ncclChar, r, c->comm, c->stream));

@@ -32,6 +32,7 @@ _pp = C.POINTER(C.c_void_p)
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 # name -> argtypes; every function returns int status unless listed in _SPECIAL
 SIGNATURES = {
@@ -42,6 +43,7 @@ SIGNATURES = {
     "smi_comm_unique_id": [_p],
     "smi_comm_init": [_p, _p],
     "smi_set_exchange_callback": [_p, EXCHANGE_CB, _p],
+    "smi_set_alltoall_callback": [_p, ALLTOALL_CB],
     "smi_allreduce_f64": [_p, _dp, _i, _i],
     "smi_malloc": [_p, _sz, _pp],
     "smi_free": [_p, _p],

@@ -99,8 +99,29 @@ class DeviceContext:
                 self._cb_error = exc
                 return 1
 
+        def alltoall(_user, send, recv, nbytes):
+            try:
+                P, r = self.nranks, self.rank
+                host = np.empty(P * nbytes, dtype=np.uint8)
+                call("smi_memcpy_d2h", self.handle, host.ctypes.data, send, P * nbytes)
+                out = np.empty(P * nbytes, dtype=np.uint8)
+                out[r * nbytes : (r + 1) * nbytes] = host[r * nbytes : (r + 1) * nbytes]
+                sends = {p: host[p * nbytes : (p + 1) * nbytes] for p in range(P) if p != r}
+                recvs = {p: out[p * nbytes : (p + 1) * nbytes] for p in range(P) if p != r}
+                self.world.sendrecv(sends, recvs)
+                call("smi_memcpy_h2d", self.handle, recv, out.ctypes.data, P * nbytes)
+                return 0
+            except Exception as exc:
+                import traceback
+
+                traceback.print_exc()
+                self._cb_error = exc
+                return 1
+
         self._cb = _lib.EXCHANGE_CB(exchange)
+        self._cb2 = _lib.ALLTOALL_CB(alltoall)
         call("smi_set_exchange_callback", self.handle, self._cb, None)
+        call("smi_set_alltoall_callback", self.handle, self._cb2)
         self.transport = "host"
 
     def allreduce(self, value, op):

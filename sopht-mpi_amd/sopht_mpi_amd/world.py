@@ -4,13 +4,23 @@ datatypes (bcast, allreduce, Send/Recv of numpy arrays).
 
 Two implementations:
   * ``SingleWorld``  - one process.
-  * ``TorchWorld``   - one process per GPU, launched by ``torch.distributed.run``; uses a
-    gloo group on CPU tensors only.  It carries the RCCL unique id at start-up and the
-    host-staged transport; bulk GPU data goes through RCCL inside libsophtmi.
+  * ``SocketWorld``  - one process per GPU, started by any launcher that exports RANK,
+    WORLD_SIZE, MASTER_ADDR and MASTER_PORT (``python -m torch.distributed.run`` does).  Plain
+    TCP sockets in a full mesh; it carries the RCCL unique id at start-up, scalar reductions
+    and the host-staged test transport.  Bulk GPU data goes through RCCL inside libsophtmi.
+    The worker processes never import torch: a second HIP runtime in the process (torch
+    bundles its own) is exactly what this library must not share an address space with.
 """
 import os
+import pickle
+import socket
+import struct
+import threading
+import time
 
 import numpy as np
+
+_PORT_OFFSET = 101  # the launcher's own store listens on MASTER_PORT
 
 
 class SingleWorld:
@@ -34,57 +44,111 @@ class SingleWorld:
         assert not send_arrays and not recv_arrays
 
 
-class TorchWorld:
-    def __init__(self):
-        import torch.distributed as dist
+def _recv_exact(sock, n):
+    buf = bytearray(n)
+    view = memoryview(buf)
+    got = 0
+    while got < n:
+        k = sock.recv_into(view[got:], n - got)
+        if k == 0:
+            raise ConnectionError("peer closed the connection")
+        got += k
+    return buf
 
-        self._dist = dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="gloo")
-        self.rank = dist.get_rank()
-        self.size = dist.get_world_size()
 
-    def bcast_bytes(self, data, root=0):
-        import torch
+class SocketWorld:
+    def __init__(self, rank=None, size=None, addr=None, port=None, timeout=120.0):
+        self.rank = int(os.environ["RANK"]) if rank is None else rank
+        self.size = int(os.environ["WORLD_SIZE"]) if size is None else size
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1") if addr is None else addr
+        base = (int(os.environ.get("MASTER_PORT", "29500")) if port is None else port) + _PORT_OFFSET
+        self._peers = {}
+        server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        server.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", base + self.rank))
+        server.listen(self.size)
+        # connect to every lower rank, accept every higher rank
+        for peer in range(self.rank):
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((addr, base + peer), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.settimeout(None)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack("<i", self.rank))
+            self._peers[peer] = s
+        server.settimeout(timeout)
+        for _ in range(self.size - 1 - self.rank):
+            s, _addr = server.accept()
+            s.settimeout(None)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            (peer,) = struct.unpack("<i", bytes(_recv_exact(s, 4)))
+            self._peers[peer] = s
+        server.close()
 
-        n = len(data)
-        t = torch.frombuffer(bytearray(data), dtype=torch.uint8).clone() if self.rank == root else torch.zeros(
-            n, dtype=torch.uint8
-        )
-        self._dist.broadcast(t, src=root)
-        return bytes(t.numpy().tobytes())
+    # -- point to point ---------------------------------------------------------------
+    def _send(self, peer, data):
+        self._peers[peer].sendall(struct.pack("<q", len(data)))
+        self._peers[peer].sendall(data)
 
-    def bcast_object(self, obj, root=0):
-        box = [obj]
-        self._dist.broadcast_object_list(box, src=root)
-        return box[0]
-
-    def allreduce(self, value, op="sum"):
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        rop = {"sum": self._dist.ReduceOp.SUM, "min": self._dist.ReduceOp.MIN, "max": self._dist.ReduceOp.MAX}[op]
-        self._dist.all_reduce(t, op=rop)
-        return float(t.item())
-
-    def barrier(self):
-        self._dist.barrier()
+    def _recv(self, peer):
+        (n,) = struct.unpack("<q", bytes(_recv_exact(self._peers[peer], 8)))
+        return _recv_exact(self._peers[peer], n)
 
     def sendrecv(self, send_arrays, recv_arrays):
-        """Exchange host numpy arrays with peers (non-blocking pairs, then wait)."""
-        import torch
-
-        reqs, recv_t = [], {}
-        for peer, arr in recv_arrays.items():
-            t = torch.from_numpy(arr.reshape(-1).view(np.uint8))
-            recv_t[peer] = t
-            reqs.append(self._dist.irecv(t, src=peer))
+        """Exchange host numpy arrays with peers: sends run on helper threads, receives here."""
+        threads = []
         for peer, arr in send_arrays.items():
-            t = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1).view(np.uint8))
-            reqs.append(self._dist.isend(t, dst=peer))
-        for r in reqs:
-            r.wait()
+            data = memoryview(np.ascontiguousarray(arr)).cast("B")
+            t = threading.Thread(target=self._send, args=(peer, data))
+            t.start()
+            threads.append(t)
+        for peer, arr in recv_arrays.items():
+            buf = self._recv(peer)
+            flat = arr.reshape(-1).view(np.uint8)
+            if len(buf) != flat.size:
+                raise ValueError(f"size mismatch in sendrecv from rank {peer}: {len(buf)} != {flat.size}")
+            flat[:] = np.frombuffer(buf, dtype=np.uint8)
+        for t in threads:
+            t.join()
+
+    # -- collectives --------------------------------------------------------------------
+    def bcast_bytes(self, data, root=0):
+        if self.rank == root:
+            for peer in self._peers:
+                self._send(peer, data)
+            return bytes(data)
+        return bytes(self._recv(root))
+
+    def bcast_object(self, obj, root=0):
+        return pickle.loads(self.bcast_bytes(pickle.dumps(obj) if self.rank == root else b"", root))
+
+    def allreduce(self, value, op="sum"):
+        fn = {"sum": sum, "min": min, "max": max}[op]
+        if self.rank == 0:
+            vals = [float(value)] + [struct.unpack("<d", bytes(self._recv(p)))[0] for p in sorted(self._peers)]
+            out = float(fn(vals))
+            for p in self._peers:
+                self._send(p, struct.pack("<d", out))
+            return out
+        self._send(0, struct.pack("<d", float(value)))
+        return struct.unpack("<d", bytes(self._recv(0)))[0]
+
+    def barrier(self):
+        self.allreduce(0.0, "sum")
+
+    def close(self):
+        for s in self._peers.values():
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers = {}
 
 
 _default = None
@@ -94,7 +158,7 @@ def get_world():
     """World of this process: multi-rank when launched with WORLD_SIZE > 1, else single."""
     global _default
     if _default is None:
-        _default = TorchWorld() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else SingleWorld()
+        _default = SocketWorld() if int(os.environ.get("WORLD_SIZE", "1")) > 1 else SingleWorld()
     return _default
 
 

@@ -1,0 +1,91 @@
+"""Worker of the multi-rank GPU test: P ranks share the one GPU of the test box, each owns a
+z-slab, transport is host-staged through the socket world.  Rank 0 gathers the slabs and
+compares with the single-rank oracle on the global grid (the reference's test strategy:
+MPI operator on scattered slabs == serial operator on the gathered array)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sopht-mpi_amd"), os.path.join(ROOT, "tests")]
+os.environ["SOPHT_MI_TRANSPORT"] = os.environ.get("SOPHT_MI_TRANSPORT", "host")
+
+from helpers import assert_close  # noqa: E402
+from oracle.flow_3d import FlowSimulator3D as OracleSim  # noqa: E402
+from sopht_mpi_amd.simulator import (  # noqa: E402
+    PrescribedForcingGrid,
+    RigidBodyFlowInteractionMPI,
+    UnboundedFlowSimulator3D,
+)
+from sopht_mpi_amd.utils import MPIFieldCommunicator3D  # noqa: E402
+from sopht_mpi_amd.world import get_world  # noqa: E402
+from oracle import immersed_boundary as oib  # noqa: E402
+
+world = get_world()
+rank, size = world.rank, world.size
+real_t = np.float32
+n = (32, 16, 32)
+flow_type = sys.argv[1] if len(sys.argv) > 1 else "navier_stokes"
+fused = (sys.argv[2] == "fused") if len(sys.argv) > 2 else True
+kw = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, flow_type=flow_type, real_t=real_t,
+          with_free_stream_flow=True, filter_vorticity=True, filter_setting_dict={"order": 1, "type": "multiplicative"})
+gpu = UnboundedFlowSimulator3D(fused_step=fused, **kw)
+assert gpu.unbounded_poisson_solver.backend == "pruned"
+assert list(gpu.mpi_construct.local_grid_size) == [n[0] // size, n[1], n[2]]
+g = gpu.ghost_size
+comm = MPIFieldCommunicator3D(g, gpu.mpi_construct)
+rng = np.random.default_rng(7)
+cpu = OracleSim(**kw)
+x, y, z = cpu.position_field
+w0 = np.zeros(cpu.vorticity_field.shape, dtype=real_t)
+for k in range(3):
+    c = rng.uniform(0.35, 0.65, 3)
+    w0[k] = rng.uniform(-1, 1) * np.exp(-((x - c[0]) ** 2 + (y - c[1] * 0.5) ** 2 + (z - c[2]) ** 2) / (2 * 0.07**2))
+inner = (slice(None),) + (slice(g, -g),) * 3
+comm.scatter_global_vector_field(gpu.vorticity_field, w0[inner])
+cpu.vorticity_field[inner] = w0[inner]
+fs = np.array([1.0, 0.25, -0.5])
+gpu.compute_flow_velocity(free_stream_velocity=fs)
+cpu.compute_flow_velocity(free_stream_velocity=fs)
+
+interactor = None
+if flow_type == "navier_stokes_with_forcing":
+    theta = np.linspace(0, 2 * np.pi, 60, endpoint=False)
+    # a ring that crosses every slab boundary (z extent 0.2 .. 0.8 of the unit z range)
+    pos = np.stack([0.5 + 0.2 * np.cos(theta), 0.25 + 0.1 * np.sin(theta), 0.5 + 0.3 * np.sin(theta)])
+    interactor = RigidBodyFlowInteractionMPI(
+        mpi_construct=gpu.mpi_construct, mpi_ghost_exchange_communicator=gpu.mpi_ghost_exchange_communicator,
+        rigid_body=None, eul_grid_forcing_field=gpu.eul_grid_forcing_field,
+        eul_grid_velocity_field=gpu.velocity_field, virtual_boundary_stiffness_coeff=-2e2,
+        virtual_boundary_damping_coeff=-1e1, dx=gpu.dx, grid_dim=3, forcing_grid_cls=PrescribedForcingGrid,
+        positions=pos, max_spacing=float(gpu.dx))
+    ref = oib.VirtualBoundaryForcing(-2e2 * float(gpu.dx) ** 2, -1e1 * float(gpu.dx) ** 2, 3, cpu.dx, pos.shape[1], g,
+                                     eul_real_t=real_t)
+
+for step in range(3):
+    dt = cpu.compute_stable_timestep(dt_prefac=0.5)
+    dt_gpu = gpu.compute_stable_timestep(dt_prefac=0.5)
+    assert abs(dt_gpu - dt) <= 1e-5 * dt, (dt_gpu, dt)
+    if interactor is not None:
+        interactor.time_step(dt)
+        interactor()
+        ref.time_step(dt)
+        ref.compute_interaction_force_on_eul_and_lag_grid(cpu.eul_grid_forcing_field, cpu.velocity_field, pos,
+                                                          np.zeros_like(pos))
+        if rank == 0:
+            assert_close(interactor.global_lag_grid_forcing_field, ref.lag_forcing, np.float64, factor=1e7,
+                         what=f"lag forcing step {step}")
+    gpu.time_step(dt=dt, free_stream_velocity=fs)
+    cpu.time_step(dt=dt, free_stream_velocity=fs)
+    got_w = np.zeros((3,) + n, dtype=real_t) if rank == 0 else None
+    got_u = np.zeros((3,) + n, dtype=real_t) if rank == 0 else None
+    comm.gather_local_vector_field(got_w, gpu.vorticity_field)
+    comm.gather_local_vector_field(got_u, gpu.velocity_field)
+    if rank == 0:
+        assert_close(got_w, cpu.vorticity_field[inner], real_t, factor=2.0 + step, what=f"vorticity step {step}")
+        assert_close(got_u, cpu.velocity_field[inner], real_t, factor=4.0 + step, what=f"velocity step {step}")
+mv = gpu.get_max_vorticity()
+assert abs(float(mv) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(float(cpu.get_max_vorticity()))
+world.barrier()
+print(f"rank {rank} ok")

