@@ -53,35 +53,6 @@ __device__ __forceinline__ Cx<T> mul_si(Cx<T> a) {
   return SIGN < 0 ? Cx<T>{a.y, -a.x} : Cx<T>{-a.y, a.x};
 }
 
-struct FftPlan {
-  int L, L8, nstages;
-  int radix[5];
-};
-
-FftPlan make_plan(int L) {
-  FftPlan p;
-  p.L = L;
-  p.L8 = L / 8;
-  p.nstages = 0;
-  int lg = 0;
-  while ((1 << lg) < L) ++lg;
-  while (lg >= 3) {
-    p.radix[p.nstages++] = 8;
-    lg -= 3;
-  }
-  if (lg == 2) p.radix[p.nstages++] = 4;
-  if (lg == 1) p.radix[p.nstages++] = 2;
-  return p;
-}
-
-// tw4[k] = exp(-2 pi i k / (4L)), k in [0, 4L); SIGN > 0 conjugates.
-template <int SIGN, typename T>
-__device__ __forceinline__ Cx<T> twl(const Cx<T>* __restrict__ tw4, int idx) {
-  Cx<T> w = tw4[idx];
-  if (SIGN > 0) w.y = -w.y;
-  return w;
-}
-
 template <int SIGN, typename T>
 __device__ __forceinline__ void dft4(Cx<T>& x0, Cx<T>& x1, Cx<T>& x2, Cx<T>& x3) {
   Cx<T> t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = mul_si<SIGN>(x1 - x3);
@@ -111,20 +82,84 @@ __device__ __forceinline__ void dft8(Cx<T> (&v)[8]) {
   v[7] = e3 - t3;
 }
 
-// One Stockham stage for the work item that owns elements u + m * L/8 (m = 0..7).
-// Inputs in v; outputs back in v, pos[m] = their position in the stage's output sequence.
-// Radix-R butterfly j takes inputs j + r * L/R, multiplies input r by w_{Ns R}^{r k}
-// (k = j mod Ns) and writes (j - k) R + k + r Ns.  With R < 8 the item runs 8/R butterflies
-// j = u + q L/8, which own exactly the same eight elements.
-template <int SIGN, typename T>
-__device__ __forceinline__ void butterflies(Cx<T> (&v)[8], int (&pos)[8], int u, int R, int Ns, const FftPlan& P,
-                                            const Cx<T>* __restrict__ tw4) {
+// Compile-time plan of an L = 2^LG point transform: radix-8 stages, then one radix-4 or
+// radix-2 stage for the remainder.  Every index below folds to constants.
+template <int LG>
+struct Plan {
+  static constexpr int L = 1 << LG, L8 = L / 8, N8 = LG / 3, REM = LG % 3, NST = N8 + (REM ? 1 : 0);
+  static constexpr int radix(int s) { return s < N8 ? 8 : (1 << REM); }
+  static constexpr int ns(int s) {  // product of the radices before stage s
+    int n = 1;
+    for (int i = 0; i < s; ++i) n *= radix(i);
+    return n;
+  }
+};
+
+// Position of output m of stage S for the work item that owns elements u + m L/8.
+// Radix-R butterfly j takes inputs j + r L/R, multiplies input r by w_{Ns R}^{r k} (k = j mod
+// Ns) and writes (j - k) R + k + r Ns.  With R < 8 the item runs 8/R butterflies
+// j = u + q L/8, which own exactly the same eight elements (m = q + (8/R) r).
+template <int LG, int S>
+__device__ __forceinline__ int stage_pos(int u, int m) {
+  constexpr int R = Plan<LG>::radix(S), Ns = Plan<LG>::ns(S), L8 = Plan<LG>::L8;
   if (R == 8) {
     const int k = u & (Ns - 1);
-    if (Ns > 1) {
-      const int step = (P.L / (Ns * 8)) * 4 * k;
-      Cx<T> w1 = twl<SIGN>(tw4, step), w2 = twl<SIGN>(tw4, 2 * step), w4 = twl<SIGN>(tw4, 4 * step);
-      Cx<T> w3 = w1 * w2, w5 = w4 * w1, w6 = w4 * w2, w7 = w4 * w3;
+    return (u - k) * 8 + k + m * Ns;
+  } else if (R == 4) {
+    const int j = u + (m & 1) * L8, k = j & (Ns - 1);
+    return (j - k) * 4 + k + (m >> 1) * Ns;
+  } else {
+    const int j = u + (m & 3) * L8, k = j & (Ns - 1);
+    return (j - k) * 2 + k + (m >> 2) * Ns;
+  }
+}
+
+// Per-thread stage twiddles (forward sign), loaded once per kernel from
+// tw4[k] = exp(-2 pi i k / (4L)).  Radix 8 keeps w, w^2, w^4 and forms the other powers
+// with four complex products.
+template <typename T, int LG>
+struct Twiddles {
+  Cx<T> w[Plan<LG>::NST > 1 ? Plan<LG>::NST : 1][4];
+};
+
+template <typename T, int LG, int S>
+__device__ __forceinline__ void load_stage_tw(Twiddles<T, LG>& tw, int u, const Cx<T>* __restrict__ tw4) {
+  if constexpr (S < Plan<LG>::NST) {
+    if constexpr (S > 0) {
+      constexpr int R = Plan<LG>::radix(S), Ns = Plan<LG>::ns(S), L = Plan<LG>::L, L8 = Plan<LG>::L8;
+      if (R == 8) {
+        const int step = (L / (Ns * 8)) * 4 * (u & (Ns - 1));
+        tw.w[S][0] = tw4[step];
+        tw.w[S][1] = tw4[2 * step];
+        tw.w[S][2] = tw4[4 * step];
+      } else if (R == 4) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int step = (L / Ns) * ((u + q * L8) & (Ns - 1));
+          tw.w[S][2 * q] = tw4[step];
+          tw.w[S][2 * q + 1] = tw4[2 * step];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tw.w[S][q] = tw4[(2 * L / Ns) * ((u + q * L8) & (Ns - 1))];
+      }
+    }
+    load_stage_tw<T, LG, S + 1>(tw, u, tw4);
+  }
+}
+
+template <int SIGN, typename T>
+__device__ __forceinline__ Cx<T> sgn(Cx<T> w) {
+  return SIGN > 0 ? Cx<T>{w.x, -w.y} : w;
+}
+
+template <int SIGN, int LG, int S, typename T>
+__device__ __forceinline__ void butterflies(Cx<T> (&v)[8], const Twiddles<T, LG>& tw) {
+  constexpr int R = Plan<LG>::radix(S);
+  if constexpr (R == 8) {
+    if constexpr (S > 0) {
+      const Cx<T> w1 = sgn<SIGN>(tw.w[S][0]), w2 = sgn<SIGN>(tw.w[S][1]), w4 = sgn<SIGN>(tw.w[S][2]);
+      const Cx<T> w3 = w1 * w2, w5 = w4 * w1, w6 = w4 * w2, w7 = w4 * w3;
       v[1] = v[1] * w1;
       v[2] = v[2] * w2;
       v[3] = v[3] * w3;
@@ -134,176 +169,155 @@ __device__ __forceinline__ void butterflies(Cx<T> (&v)[8], int (&pos)[8], int u,
       v[7] = v[7] * w7;
     }
     dft8<SIGN>(v);
-    const int j0 = (u - k) * 8 + k;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) pos[r] = j0 + r * Ns;
-  } else if (R == 4) {
+  } else if constexpr (R == 4) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int j = u + q * P.L8, k = j & (Ns - 1);
-      if (Ns > 1) {
-        const int step = (P.L / (Ns * 4)) * 4 * k;
-        Cx<T> w1 = twl<SIGN>(tw4, step), w2 = twl<SIGN>(tw4, 2 * step);
-        Cx<T> w3 = w1 * w2;
+      if constexpr (S > 0) {
+        const Cx<T> w1 = sgn<SIGN>(tw.w[S][2 * q]), w2 = sgn<SIGN>(tw.w[S][2 * q + 1]);
         v[q + 2] = v[q + 2] * w1;
         v[q + 4] = v[q + 4] * w2;
-        v[q + 6] = v[q + 6] * w3;
+        v[q + 6] = v[q + 6] * (w1 * w2);
       }
       dft4<SIGN>(v[q], v[q + 2], v[q + 4], v[q + 6]);
-      const int j0 = (j - k) * 4 + k;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pos[q + 2 * r] = j0 + r * Ns;
     }
   } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int j = u + q * P.L8, k = j & (Ns - 1);
       Cx<T> b = v[q + 4];
-      if (Ns > 1) b = b * twl<SIGN>(tw4, (P.L / (Ns * 2)) * 4 * k);
-      Cx<T> a = v[q];
+      if constexpr (S > 0) b = b * sgn<SIGN>(tw.w[S][q]);
+      const Cx<T> a = v[q];
       v[q] = a + b;
       v[q + 4] = a - b;
-      const int j0 = (j - k) * 2 + k;
-      pos[q] = j0;
-      pos[q + 4] = j0 + Ns;
     }
   }
 }
 
 constexpr int kThreads = 256;      // pointwise helper kernels
-constexpr int kMaxThreads = 1024;  // FFT kernels: one work item per thread, TS * L / 8 threads
+constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per thread
 
-// The work item of this thread: sequence t (fastest over lanes) and element group u.
-struct Items {
-  int ts_mask, ts_shift;
-  __device__ __forceinline__ int t(int) const { return threadIdx.x & ts_mask; }
-  __device__ __forceinline__ int u(int) const { return threadIdx.x >> ts_shift; }
-};
+#ifndef SMI_FFT_COLS_F32
+#define SMI_FFT_COLS_F32 16
+#endif
+// Sequences per tile.  Column passes want >= 16 (f32) / 8 (f64) so that every row of the tile
+// is a whole 128-byte line; TS * L / 8 threads, at most 1024.
+constexpr int tile_seqs(int L, bool f32, bool rows) {
+  int want = rows ? 4 : (f32 ? SMI_FFT_COLS_F32 : 8);
+  int ts = 2048 / L > want ? 2048 / L : want;
+  if (ts * L / 8 > kMaxThreads) ts = kMaxThreads * 8 / L;
+  return ts < 1 ? 1 : ts;
+}
 
-// All stages of one batched FFT.  LDS tile layout: lds[pos * TSP + t].
+// All stages of one batched FFT, stage S onward.  LDS tile layout: lds[pos * TSP + t].
 // FIRST_FROM_LDS: stage 0 inputs are read from the tile (the caller filled it and must NOT
-// have synchronised) instead of being supplied in v.  On return v / pos hold the last
-// stage's outputs; every read of the tile has completed (barrier), so the caller may
-// overwrite it.
-template <int SIGN, bool FIRST_FROM_LDS, int BPT, typename T>
-__device__ __forceinline__ void fft_run(Cx<T> (&v)[BPT][8], int (&pos)[BPT][8], const FftPlan& P, Cx<T>* lds,
-                                        int TSP, const Items& it, const Cx<T>* __restrict__ tw4) {
-  int Ns = 1;
-  for (int s = 0; s < P.nstages; ++s) {
-    if (s > 0 || FIRST_FROM_LDS) {
-      if (s > 0) {
+// have synchronised) instead of being supplied in v.  On return v holds the last stage's
+// outputs (output m at position stage_pos<LG, NST-1>(u, m)); every read of the tile has
+// completed (barrier), so the caller may overwrite it.
+template <int SIGN, bool FIRST_FROM_LDS, int LG, int TSP, int S, typename T>
+__device__ __forceinline__ void fft_run_from(Cx<T> (&v)[8], Cx<T>* lds, int t, int u, const Twiddles<T, LG>& tw) {
+  if constexpr (S < Plan<LG>::NST) {
+    if constexpr (S > 0 || FIRST_FROM_LDS) {
+      if constexpr (S > 0) {
 #pragma unroll
-        for (int i = 0; i < BPT; ++i) {
-          const int t = it.t(i);
-#pragma unroll
-          for (int m = 0; m < 8; ++m) lds[pos[i][m] * TSP + t] = v[i][m];
-        }
+        for (int m = 0; m < 8; ++m) lds[stage_pos<LG, S - 1>(u, m) * TSP + t] = v[m];
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < BPT; ++i) {
-        const int t = it.t(i), u = it.u(i);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) v[i][m] = lds[(u + m * P.L8) * TSP + t];
-      }
+      for (int m = 0; m < 8; ++m) v[m] = lds[(u + m * Plan<LG>::L8) * TSP + t];
       __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) butterflies<SIGN>(v[i], pos[i], it.u(i), P.radix[s], Ns, P, tw4);
-    Ns *= P.radix[s];
+    butterflies<SIGN, LG, S>(v, tw);
+    fft_run_from<SIGN, FIRST_FROM_LDS, LG, TSP, S + 1>(v, lds, t, u, tw);
   }
+}
+template <int SIGN, bool FIRST_FROM_LDS, int LG, int TSP, typename T>
+__device__ __forceinline__ void fft_run(Cx<T> (&v)[8], Cx<T>* lds, int t, int u, const Twiddles<T, LG>& tw) {
+  fft_run_from<SIGN, FIRST_FROM_LDS, LG, TSP, 0>(v, lds, t, u, tw);
+}
+template <int LG>
+__device__ __forceinline__ int out_pos(int u, int m) {
+  return stage_pos<LG, Plan<LG>::NST - 1>(u, m);
 }
 
 // Geometry of the spectral buffers.
 //   bufA (exchange layout) : [rank P][comp nc][z nzl][y ny][KXP]      x_fwd out, x_inv in
 //   bufT (after all-to-all): [slab P][comp nc][z nzl][y ny][KXP]      y_fwd in, y_inv out
-//   bufB                   : [comp nc][z nz][ky' 2ny][KXP]            z_conv in place
-//   green                  : [kz folded nz+1][ky folded ny+1][KXP]    real
+//   bufB                   : [comp nc][z / ZB][ky' 2ny][z % ZB][KXP]   z_conv in place; blocked in z so
+//                            that neither a y tile (all ky' of one z) nor a z tile (all z of one
+//                            ky') strides over more than a few dozen pages
+//   green                  : [ky folded ny+1][kz folded nz+1][KXP]    real
 // KXL = spectral columns per rank (kx in parity-split order j = 0..nx, cut into P ranges),
 // KXP = row pitch (KXL rounded up to 16 columns).
 struct PGeo {
-  int nz, ny, nx, nzl, P, nc, KXL, KXP;
+  int nz, ny, nx, nzl, P, nc, KXL, KXP, zb_shift;
 };
 
+// element offset of bufB row (c, z, ky')
+__device__ __forceinline__ size_t rowB(const PGeo& G, int c, int z, int kyp) {
+  const int ZB = 1 << G.zb_shift;
+  return ((((size_t)c * (G.nz >> G.zb_shift) + (z >> G.zb_shift)) * (2 * G.ny) + kyp) * ZB + (z & (ZB - 1))) *
+         (size_t)G.KXP;
+}
+
+#define FFT_KERNEL_PROLOGUE(ROWS)                                                  \
+  constexpr int L = Plan<LG>::L, L8 = Plan<LG>::L8;                                \
+  constexpr int TS = tile_seqs(L, sizeof(T) == 4, ROWS), NT = TS * L / 8;          \
+  extern __shared__ char smem[];                                                   \
+  Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);                                     \
+  const int t = threadIdx.x & (TS - 1), u = threadIdx.x / TS;                      \
+  Twiddles<T, LG> tw;                                                              \
+  load_stage_tw<T, LG, 0>(tw, u, tw4);                                             \
+  (void)L8; (void)NT;
+
 // ------------------------------------------------------------------------- y forward
-template <typename T, int BPT>
-__global__ void __launch_bounds__(kMaxThreads) k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out,
-                                                        PGeo G, FftPlan P, const Cx<T>* __restrict__ tw4, int ts_shift) {
-  extern __shared__ char smem[];
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
-  const int TS = 1 << ts_shift;
-  const Items it{TS - 1, ts_shift};
-  const int c = blockIdx.z, z = blockIdx.y, kx0 = blockIdx.x * TS;
-  const Cx<T>* src = in + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP;
-  Cx<T>* dst = out + (((size_t)c * G.nz + z) * (2 * G.ny)) * (size_t)G.KXP;
-  Cx<T> v[BPT][8], a0[BPT][8];
-  int pos[BPT][8];
+template <typename T, int LG>
+__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1 << LG) / 8)
+    k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
+  FFT_KERNEL_PROLOGUE(false)
+  const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
+  const bool ok = col < G.KXL;
+  const Cx<T>* src = in + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP + col;
+  Cx<T>* dst = out + rowB(G, c, z, 0) + col;
+  const size_t kystride = (size_t)G.KXP << G.zb_shift;
+  Cx<T> v[8], a0[8];
   // the column is read once and kept in registers for both parities
 #pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int col = kx0 + it.t(i), u = it.u(i);
-    const bool ok = col < G.KXL;
+  for (int m = 0; m < 8; ++m) a0[m] = ok ? src[(size_t)(u + m * L8) * G.KXP] : Cx<T>{0, 0};
 #pragma unroll
-    for (int m = 0; m < 8; ++m) a0[i][m] = ok ? src[(size_t)(u + m * P.L8) * G.KXP + col] : Cx<T>{0, 0};
-  }
   for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int u = it.u(i);
+    for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * tw4[2 * (u + m * L8)] : a0[m];
+    fft_run<-1, false, LG, TS>(v, lds, t, u, tw);
+    if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[i][m] = parity ? a0[i][m] * tw4[2 * (u + m * P.L8)] : a0[i][m];
-    }
-    fft_run<-1, false, BPT>(v, pos, P, lds, TS, it, tw4);
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int col = kx0 + it.t(i);
-      if (col < G.KXL) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) dst[(size_t)(parity * P.L + pos[i][m]) * G.KXP + col] = v[i][m];
-      }
+      for (int m = 0; m < 8; ++m) dst[(size_t)(parity * L + out_pos<LG>(u, m)) * kystride] = v[m];
     }
   }
 }
 
 // ------------------------------------------------------------------------- y inverse
-template <typename T, int BPT>
-__global__ void __launch_bounds__(kMaxThreads) k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out,
-                                                        PGeo G, FftPlan P, const Cx<T>* __restrict__ tw4, int ts_shift) {
-  extern __shared__ char smem[];
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
-  const int TS = 1 << ts_shift;
-  const Items it{TS - 1, ts_shift};
-  const int c = blockIdx.z, z = blockIdx.y, kx0 = blockIdx.x * TS;
-  const Cx<T>* src = in + (((size_t)c * G.nz + z) * (2 * G.ny)) * (size_t)G.KXP;
-  Cx<T>* dst = out + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP;
-  Cx<T> v[BPT][8], res[BPT][8];
-  int pos[BPT][8];
+template <typename T, int LG>
+__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1 << LG) / 8)
+    k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
+  FFT_KERNEL_PROLOGUE(false)
+  const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
+  const bool ok = col < G.KXL;
+  const Cx<T>* src = in + rowB(G, c, z, 0) + col;
+  const size_t kystride = (size_t)G.KXP << G.zb_shift;
+  Cx<T>* dst = out + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP + col;
+  Cx<T> v[8], res[8];
+#pragma unroll
   for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int col = kx0 + it.t(i), u = it.u(i);
-      const bool ok = col < G.KXL;
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-        v[i][m] = ok ? src[(size_t)(parity * P.L + u + m * P.L8) * G.KXP + col] : Cx<T>{0, 0};
-    }
-    fft_run<+1, false, BPT>(v, pos, P, lds, TS, it, tw4);
+    for (int m = 0; m < 8; ++m) v[m] = ok ? src[(size_t)(parity * L + u + m * L8) * kystride] : Cx<T>{0, 0};
+    fft_run<+1, false, LG, TS>(v, lds, t, u, tw);
     if (parity == 0) {
 #pragma unroll
-      for (int i = 0; i < BPT; ++i)
+      for (int m = 0; m < 8; ++m) res[m] = v[m];
+    } else if (ok) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) res[i][m] = v[i][m];
-    } else {
-#pragma unroll
-      for (int i = 0; i < BPT; ++i) {
-        const int col = kx0 + it.t(i);
-        if (col < G.KXL) {
-#pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            const int n = pos[i][m];
-            dst[(size_t)n * G.KXP + col] = res[i][m] + conj(tw4[2 * n]) * v[i][m];
-          }
-        }
+      for (int m = 0; m < 8; ++m) {
+        const int n = out_pos<LG>(u, m);
+        dst[(size_t)n * G.KXP] = res[m] + conj(tw4[2 * n]) * v[m];
       }
     }
   }
@@ -311,68 +325,45 @@ __global__ void __launch_bounds__(kMaxThreads) k_fft_y_inv(const Cx<T>* __restri
 
 // ------------------------------------------------------------------------- z convolution
 // forward nz -> 2nz, multiply by the folded Green's table, inverse 2nz -> nz, in place.
-template <typename T, int BPT>
-__global__ void __launch_bounds__(kMaxThreads) k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G,
-                                                         FftPlan P, const Cx<T>* __restrict__ tw4, int ts_shift) {
-  extern __shared__ char smem[];
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
-  const int TS = 1 << ts_shift;
-  const Items it{TS - 1, ts_shift};
-  const int c = blockIdx.z, kyp = blockIdx.y, kx0 = blockIdx.x * TS;
-  const size_t zstride = (size_t)2 * G.ny * G.KXP;
-  Cx<T>* base = buf + ((size_t)c * G.nz * 2 * G.ny + kyp) * (size_t)G.KXP;
+template <typename T, int LG>
+__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1 << LG) / 8)
+    k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
+  FFT_KERNEL_PROLOGUE(false)
+  const int c = blockIdx.z, kyp = blockIdx.y, col = blockIdx.x * TS + t;
+  const bool ok = col < G.KXL;
+  Cx<T>* base = buf + col;
+  auto zoff = [&](int z) { return rowB(G, c, z, kyp); };
   const int ky = 2 * (kyp % G.ny) + kyp / G.ny;
   const int kyc = ky <= G.ny ? ky : 2 * G.ny - ky;
-  const T* gbase = green + (size_t)kyc * G.KXP;
-  const size_t gstride = (size_t)(G.ny + 1) * G.KXP;
-  Cx<T> v[BPT][8], res[BPT][8], a0[BPT][8];
-  int pos[BPT][8];
+  const T* gbase = green + (size_t)kyc * (G.nz + 1) * G.KXP + col;  // all kz of this ky are contiguous rows
+  const size_t gstride = (size_t)G.KXP;
+  Cx<T> v[8], res[8], a0[8];
   // the column is read once and kept in registers for both parities
 #pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int col = kx0 + it.t(i), u = it.u(i);
-    const bool ok = col < G.KXL;
+  for (int m = 0; m < 8; ++m) a0[m] = ok ? base[zoff(u + m * L8)] : Cx<T>{0, 0};
 #pragma unroll
-    for (int m = 0; m < 8; ++m) a0[i][m] = ok ? base[(size_t)(u + m * P.L8) * zstride + col] : Cx<T>{0, 0};
-  }
   for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int u = it.u(i);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) v[i][m] = pz ? a0[i][m] * tw4[2 * (u + m * P.L8)] : a0[i][m];
-    }
-    fft_run<-1, false, BPT>(v, pos, P, lds, TS, it, tw4);
+    for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * tw4[2 * (u + m * L8)] : a0[m];
+    fft_run<-1, false, LG, TS>(v, lds, t, u, tw);
     // spectrum at kz = 2 pos + pz, times the Green's table; into the tile in natural order
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int t = it.t(i), col = kx0 + t;
-      const bool ok = col < G.KXL;
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int kz = 2 * pos[i][m] + pz;
-        const int kzc = kz <= G.nz ? kz : 2 * G.nz - kz;
-        const T gval = ok ? gbase[(size_t)kzc * gstride + col] : T(0);
-        lds[pos[i][m] * TS + t] = scale(v[i][m], gval);
-      }
+    for (int m = 0; m < 8; ++m) {
+      const int pos = out_pos<LG>(u, m);
+      const int kz = 2 * pos + pz;
+      const int kzc = kz <= G.nz ? kz : 2 * G.nz - kz;
+      const T gval = ok ? gbase[(size_t)kzc * gstride] : T(0);
+      lds[pos * TS + t] = scale(v[m], gval);
     }
-    fft_run<+1, true, BPT>(v, pos, P, lds, TS, it, tw4);
+    fft_run<+1, true, LG, TS>(v, lds, t, u, tw);
     if (pz == 0) {
 #pragma unroll
-      for (int i = 0; i < BPT; ++i)
+      for (int m = 0; m < 8; ++m) res[m] = v[m];
+    } else if (ok) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) res[i][m] = v[i][m];
-    } else {
-#pragma unroll
-      for (int i = 0; i < BPT; ++i) {
-        const int col = kx0 + it.t(i);
-        if (col < G.KXL) {
-#pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            const int n = pos[i][m];
-            base[(size_t)n * zstride + col] = res[i][m] + conj(tw4[2 * n]) * v[i][m];
-          }
-        }
+      for (int m = 0; m < 8; ++m) {
+        const int n = out_pos<LG>(u, m);
+        base[zoff(n)] = res[m] + conj(tw4[2 * n]) * v[m];
       }
     }
   }
@@ -390,22 +381,18 @@ struct FieldGeo {
   long long plane, vol;
 };
 
-template <typename T, int BPT>
-__global__ void __launch_bounds__(kMaxThreads) k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G,
-                                                        FieldGeo F, FftPlan P, const Cx<T>* __restrict__ tw4,
-                                                        int ts_shift) {
-  extern __shared__ char smem[];
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
-  const int TS = 1 << ts_shift, TSP = TS + 1;
-  const Items it{TS - 1, ts_shift};
+template <typename T, int LG>
+__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, true) * (1 << LG) / 8)
+    k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G, FieldGeo F,
+                const Cx<T>* __restrict__ tw4) {
+  FFT_KERNEL_PROLOGUE(true)
+  constexpr int TSP = TS + 1, NW = NT / 64 > 0 ? NT / 64 : 1;
   const int c = blockIdx.z, zl = blockIdx.y, y0 = blockIdx.x * TS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int L = P.L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* fbase = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + F.g;
-  Cx<T> v[BPT][8];
-  int pos[BPT][8];
+  Cx<T> v[8];
   for (int parity = 0; parity < 2; ++parity) {
-    for (int r = wave; r < TS; r += nwaves) {
+    for (int r = wave; r < TS; r += NW) {
       const int y = y0 + r;
       const T* row = fbase + (size_t)(y + F.g) * F.px;
       for (int n = lane; n < L; n += 64) {
@@ -418,16 +405,12 @@ __global__ void __launch_bounds__(kMaxThreads) k_fft_x_fwd(const T* __restrict__
         lds[n * TSP + r] = a;
       }
     }
-    fft_run<-1, true, BPT>(v, pos, P, lds, TSP, it, tw4);
+    fft_run<-1, true, LG, TSP>(v, lds, t, u, tw);
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const int t = it.t(i);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) lds[pos[i][m] * TSP + t] = v[i][m];
-    }
+    for (int m = 0; m < 8; ++m) lds[out_pos<LG>(u, m) * TSP + t] = v[m];
     __syncthreads();
     const int cnt = L + 1 - parity;
-    for (int r = wave; r < TS; r += nwaves) {
+    for (int r = wave; r < TS; r += NW) {
       const int y = y0 + r;
       if (y >= G.ny) continue;
       for (int m = lane; m < cnt; m += 64) {
@@ -453,23 +436,19 @@ __global__ void __launch_bounds__(kMaxThreads) k_fft_x_fwd(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------- x inverse
-template <typename T, int BPT>
-__global__ void __launch_bounds__(kMaxThreads) k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G,
-                                                        FieldGeo F, FftPlan P, const Cx<T>* __restrict__ tw4,
-                                                        int ts_shift) {
-  extern __shared__ char smem[];
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);
-  const int TS = 1 << ts_shift, TSP = TS + 1;
-  const Items it{TS - 1, ts_shift};
+template <typename T, int LG>
+__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, true) * (1 << LG) / 8)
+    k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G, FieldGeo F,
+                const Cx<T>* __restrict__ tw4) {
+  FFT_KERNEL_PROLOGUE(true)
+  constexpr int TSP = TS + 1, NW = NT / 64 > 0 ? NT / 64 : 1;
   const int c = blockIdx.z, zl = blockIdx.y, y0 = blockIdx.x * TS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int L = P.L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* fbase = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + F.g;
-  Cx<T> v[BPT][8], res[BPT][8];
-  int pos[BPT][8];
+  Cx<T> v[8], res[8];
   for (int parity = 0; parity < 2; ++parity) {
     const int cnt = L + 1 - parity;
-    for (int r = wave; r < TS; r += nwaves) {
+    for (int r = wave; r < TS; r += NW) {
       const int y = y0 + r;
       for (int m = lane; m < cnt; m += 64) {
         Cx<T> a{0, 0};
@@ -485,7 +464,7 @@ __global__ void __launch_bounds__(kMaxThreads) k_fft_x_inv(const Cx<T>* __restri
     // Z[k] = E[k] + i O[k], E = (X[k] + conj X[M-k]) / 2, O = (X[k] - conj X[M-k]) / 2 * e^{+2 pi i k / 2M};
     // pairs (k, M-k) share their two inputs, so each lane rewrites one pair in place.
     const int npair = parity ? L / 2 : L / 2 + 1;
-    for (int r = wave; r < TS; r += nwaves) {
+    for (int r = wave; r < TS; r += NW) {
       for (int m = lane; m < npair; m += 64) {
         const int m2 = parity ? L - 1 - m : L - m;  // partner index in this parity block
         Cx<T> xa = lds[m * TSP + r], xb = lds[m2 * TSP + r];
@@ -500,24 +479,18 @@ __global__ void __launch_bounds__(kMaxThreads) k_fft_x_inv(const Cx<T>* __restri
         }
       }
     }
-    fft_run<+1, true, BPT>(v, pos, P, lds, TSP, it, tw4);
+    fft_run<+1, true, LG, TSP>(v, lds, t, u, tw);
     if (parity == 0) {
 #pragma unroll
-      for (int i = 0; i < BPT; ++i)
-#pragma unroll
-        for (int m = 0; m < 8; ++m) res[i][m] = v[i][m];
+      for (int m = 0; m < 8; ++m) res[m] = v[m];
     } else {
 #pragma unroll
-      for (int i = 0; i < BPT; ++i) {
-        const int t = it.t(i);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int n = pos[i][m];
-          lds[n * TSP + t] = res[i][m] + conj(tw4[2 * n]) * v[i][m];
-        }
+      for (int m = 0; m < 8; ++m) {
+        const int n = out_pos<LG>(u, m);
+        lds[n * TSP + t] = res[m] + conj(tw4[2 * n]) * v[m];
       }
       __syncthreads();
-      for (int r = wave; r < TS; r += nwaves) {
+      for (int r = wave; r < TS; r += NW) {
         const int y = y0 + r;
         if (y >= G.ny) continue;
         T* row = fbase + (size_t)(y + F.g) * F.px;
@@ -540,7 +513,7 @@ __global__ void __launch_bounds__(kThreads) k_fold_green(T* __restrict__ green, 
   if (i >= total) return;
   const int jl = (int)(i % G.KXP);
   long long r = i / G.KXP;
-  const int kyc = (int)(r % (G.ny + 1)), kzc = (int)(r / (G.ny + 1));
+  const int kzc = (int)(r % (G.nz + 1)), kyc = (int)(r / (G.nz + 1));
   const int L = G.nx / 2;
   const int j = rank * G.KXL + jl;
   T val = T(0);
@@ -552,16 +525,6 @@ __global__ void __launch_bounds__(kThreads) k_fold_green(T* __restrict__ green, 
 }
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
-
-// Sequences per tile.  Columns want >= 16 (f32) / 8 (f64) so that every row of the tile is
-// a whole 128-byte line; one work item (8 points) per thread, 256..1024 threads.
-int choose_ts(int L, bool f32, bool rows) {
-  int want = rows ? 4 : (f32 ? 16 : 8);
-  int ts = 2048 / L > want ? 2048 / L : want;
-  if (ts * L / 8 > kMaxThreads) ts = kMaxThreads * 8 / L;
-  if (ts < 1) ts = 1;
-  return ts;
-}
 
 int ilog2(int n) {
   int s = 0;
@@ -577,8 +540,7 @@ int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per
 
 struct PrunedState {
   PGeo G;
-  FftPlan px, py, pz;
-  int ts_x, ts_y, ts_z;
+  int lgx, lgy, lgz;  // log2 of the transform lengths nx/2, ny, nz
   void* tw[3] = {nullptr, nullptr, nullptr};  // x, y, z twiddle tables (4L complex each)
   void* bufA = nullptr;
   void* bufT = nullptr;  // == bufA on a single rank
@@ -613,7 +575,6 @@ int smi_pruned_destroy(smi_poisson* p) {
   return 0;
 }
 
-template <typename T, int BPT>
 static int set_lds(const void* fn, size_t bytes) {
   SMI_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return 0;
@@ -636,13 +597,10 @@ int smi_pruned_create(smi_poisson* p) {
   G.nc = 3;
   G.KXL = (G.nx + 1 + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
-  s->px = make_plan(G.nx / 2);
-  s->py = make_plan(G.ny);
-  s->pz = make_plan(G.nz);
-  const bool f32 = c->dtype == SMI_F32;
-  s->ts_x = choose_ts(s->px.L, f32, true);
-  s->ts_y = choose_ts(s->py.L, f32, false);
-  s->ts_z = choose_ts(s->pz.L, f32, false);
+  G.zb_shift = G.nz >= 16 ? 4 : ilog2(G.nz);
+  s->lgx = ilog2(G.nx / 2);
+  s->lgy = ilog2(G.ny);
+  s->lgz = ilog2(G.nz);
   const size_t cs = 2 * smi_elem_size(c);
   const size_t nA = (size_t)G.P * G.nc * G.nzl * G.ny * G.KXP;
   const size_t nB = (size_t)G.nc * G.nz * 2 * G.ny * G.KXP;
@@ -657,9 +615,9 @@ int smi_pruned_create(smi_poisson* p) {
   SMI_CHECK_HIP(hipMalloc(&s->bufB, nB * cs));
   SMI_CHECK_HIP(hipMemsetAsync(s->bufB, 0, nB * cs, c->stream));
   SMI_DISPATCH(c, {
-    SMI_CHECK(upload_twiddles<T>(c, s->px.L, &s->tw[0]));
-    SMI_CHECK(upload_twiddles<T>(c, s->py.L, &s->tw[1]));
-    SMI_CHECK(upload_twiddles<T>(c, s->pz.L, &s->tw[2]));
+    SMI_CHECK(upload_twiddles<T>(c, G.nx / 2, &s->tw[0]));
+    SMI_CHECK(upload_twiddles<T>(c, G.ny, &s->tw[1]));
+    SMI_CHECK(upload_twiddles<T>(c, G.nz, &s->tw[2]));
   });
   // Green's table: full spectrum once through rocFFT, then fold / permute / normalise
   void* ghat = nullptr;
@@ -685,65 +643,61 @@ int smi_pruned_greens_download(smi_poisson* p, void* host) {
   return smi_memcpy_d2h(p->ctx, host, p->pruned->green, p->pruned->green_bytes);
 }
 
-template <typename T, int BPT>
+template <typename T, int LG>
 static int launch_cols(smi_ctx* c, PrunedState* s, int which, int nc) {
   // which: 0 = y_fwd, 1 = z_conv, 2 = y_inv
   PGeo G = s->G;
   G.nc = nc;
-  const FftPlan& P = which == 1 ? s->pz : s->py;
-  const int TS = which == 1 ? s->ts_z : s->ts_y, ts_shift = ilog2(TS), nthreads = TS * P.L / 8;
-  const size_t lds_bytes = (size_t)P.L * TS * sizeof(Cx<T>);
+  constexpr int L = 1 << LG, TS = tile_seqs(L, sizeof(T) == 4, false), NT = TS * L / 8;
+  const size_t lds_bytes = (size_t)L * TS * sizeof(Cx<T>);
   dim3 grid((G.KXL + TS - 1) / TS, which == 1 ? 2 * G.ny : G.nz, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[which == 1 ? 2 : 1];
   if (which == 0) {
-    SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_y_fwd<T, BPT>, lds_bytes)));
+    SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG>, lds_bytes));
     SmiProfScope prof(c, PROF_FFT_Y_FWD, 6.0 * nc * smi_S(c));
-    k_fft_y_fwd<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, P, tw,
-                                                                 ts_shift);
+    k_fft_y_fwd<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, tw);
   } else if (which == 1) {
-    SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_z_conv<T, BPT>, lds_bytes)));
+    SMI_CHECK(set_lds((const void*)k_fft_z_conv<T, LG>, lds_bytes));
     SmiProfScope prof(c, PROF_FFT_Z_CONV, 9.0 * nc * smi_S(c));
-    k_fft_z_conv<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G, P, tw,
-                                                                  ts_shift);
+    k_fft_z_conv<T, LG><<<grid, NT, lds_bytes, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G, tw);
   } else {
-    SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_y_inv<T, BPT>, lds_bytes)));
+    SMI_CHECK(set_lds((const void*)k_fft_y_inv<T, LG>, lds_bytes));
     SmiProfScope prof(c, PROF_FFT_Y_INV, 6.0 * nc * smi_S(c));
-    k_fft_y_inv<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, P, tw,
-                                                                 ts_shift);
+    k_fft_y_inv<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, tw);
   }
   SMI_LAUNCH_CHECK();
   return 0;
 }
 
-template <typename T, int BPT>
+template <typename T, int LG>
 static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int nc, void* field) {
   PGeo G = s->G;
   G.nc = nc;
-  const FftPlan& P = s->px;
-  const int TS = s->ts_x, ts_shift = ilog2(TS), nthreads = TS * P.L / 8;
-  const size_t lds_bytes = (size_t)(P.L + 1) * (TS + 1) * sizeof(Cx<T>);
+  constexpr int L = 1 << LG, TS = tile_seqs(L, sizeof(T) == 4, true), NT = TS * L / 8;
+  const size_t lds_bytes = (size_t)(L + 1) * (TS + 1) * sizeof(Cx<T>);
   FieldGeo F{c->g, c->px, (long long)c->plane, (long long)c->vol};
   dim3 grid((G.ny + TS - 1) / TS, G.nzl, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[0];
   if (fwd) {
-    SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_x_fwd<T, BPT>, lds_bytes)));
+    SMI_CHECK(set_lds((const void*)k_fft_x_fwd<T, LG>, lds_bytes));
     SmiProfScope prof(c, PROF_FFT_X_FWD, 3.0 * nc * smi_S(c));
-    k_fft_x_fwd<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const T*)field, (Cx<T>*)s->bufA, G, F, P, tw,
-                                                                 ts_shift);
+    k_fft_x_fwd<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const T*)field, (Cx<T>*)s->bufA, G, F, tw);
   } else {
-    SMI_CHECK((set_lds<T, BPT>((const void*)k_fft_x_inv<T, BPT>, lds_bytes)));
+    SMI_CHECK(set_lds((const void*)k_fft_x_inv<T, LG>, lds_bytes));
     SmiProfScope prof(c, PROF_FFT_X_INV, 3.0 * nc * smi_S(c));
-    k_fft_x_inv<T, BPT><<<grid, nthreads, lds_bytes, c->stream>>>((const Cx<T>*)s->bufA, (T*)field, G, F, P, tw,
-                                                                 ts_shift);
+    k_fft_x_inv<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const Cx<T>*)s->bufA, (T*)field, G, F, tw);
   }
   SMI_LAUNCH_CHECK();
   return 0;
 }
 
-#define BPT_SWITCH(bpt, ...)            \
-  switch (bpt) {                        \
-    case 1: { constexpr int BPT = 1; __VA_ARGS__ } break; \
-    default: { constexpr int BPT = 1; __VA_ARGS__ } break; \
+#define LG_CASE(n, ...) case n: { constexpr int LG = n; __VA_ARGS__ } break;
+#define LG_SWITCH(lg, ...)                                                                      \
+  switch (lg) {                                                                                 \
+    LG_CASE(3, __VA_ARGS__) LG_CASE(4, __VA_ARGS__) LG_CASE(5, __VA_ARGS__) LG_CASE(6, __VA_ARGS__) \
+    LG_CASE(7, __VA_ARGS__) LG_CASE(8, __VA_ARGS__) LG_CASE(9, __VA_ARGS__) LG_CASE(10, __VA_ARGS__) \
+    LG_CASE(11, __VA_ARGS__)                                                                    \
+    default: smi_set_error("unsupported transform length 2^%d", lg); return 1;                  \
   }
 
 int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp) {
@@ -755,19 +709,19 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
   const size_t cs = 2 * smi_elem_size(c);
   const size_t peer_bytes = (size_t)ncomp * G.nzl * G.ny * G.KXP * cs;
   SMI_DISPATCH(c, {
-    BPT_SWITCH(1, SMI_CHECK((launch_rows<T, BPT>(c, s, true, ncomp, (void*)rhs)));)
+    LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, true, ncomp, (void*)rhs)));)
     if (G.P > 1) {
       SmiProfScope prof(c, PROF_TRANSPOSE, (double)peer_bytes * G.P);
       SMI_CHECK(smi_alltoall_impl(c, s->bufA, s->bufT, peer_bytes));
     }
-    BPT_SWITCH(1, SMI_CHECK((launch_cols<T, BPT>(c, s, 0, ncomp)));)
-    BPT_SWITCH(1, SMI_CHECK((launch_cols<T, BPT>(c, s, 1, ncomp)));)
-    BPT_SWITCH(1, SMI_CHECK((launch_cols<T, BPT>(c, s, 2, ncomp)));)
+    LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 0, ncomp)));)
+    LG_SWITCH(s->lgz, SMI_CHECK((launch_cols<T, LG>(c, s, 1, ncomp)));)
+    LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 2, ncomp)));)
     if (G.P > 1) {
       SmiProfScope prof(c, PROF_TRANSPOSE, (double)peer_bytes * G.P);
       SMI_CHECK(smi_alltoall_impl(c, s->bufT, s->bufA, peer_bytes));
     }
-    BPT_SWITCH(1, SMI_CHECK((launch_rows<T, BPT>(c, s, false, ncomp, solution)));)
+    LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, false, ncomp, solution)));)
   });
   return 0;
 }
