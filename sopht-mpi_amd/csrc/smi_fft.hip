@@ -207,36 +207,85 @@ constexpr int tile_seqs(int L, bool f32, bool rows) {
   return ts < 1 ? 1 : ts;
 }
 
-// All stages of one batched FFT, stage S onward.  LDS tile layout: lds[pos * TSP + t].
-// FIRST_FROM_LDS: stage 0 inputs are read from the tile (the caller filled it and must NOT
-// have synchronised) instead of being supplied in v.  On return v holds the last stage's
-// outputs (output m at position stage_pos<LG, NST-1>(u, m)); every read of the tile has
-// completed (barrier), so the caller may overwrite it.
-template <int SIGN, bool FIRST_FROM_LDS, int LG, int TSP, int S, typename T>
-__device__ __forceinline__ void fft_run_from(Cx<T> (&v)[8], Cx<T>* lds, int t, int u, const Twiddles<T, LG>& tw) {
+// LDS tile layouts.  Column passes: lds[pos * TSP + t], lanes run along the sequences of the
+// tile.  Row passes: one padded row per sequence, lds[t * PITCH + pos + pos / 8], lanes run
+// along the work items of a sequence; the pos / 8 skew spreads the radix-8 strided writes of
+// the autosort stages over the banks.
+template <int TSP>
+struct ColLayout {
+  static __device__ __forceinline__ int idx(int pos, int t) { return pos * TSP + t; }
+};
+template <int PITCH>
+struct RowLayout {
+  static __device__ __forceinline__ int idx(int pos, int t) { return t * PITCH + pos + (pos >> 3); }
+};
+
+// Hands out the tile for the next exchange.  With two tiles (PP) consecutive exchanges
+// alternate between them, so a wave may start writing the next exchange while slower waves
+// still read the previous one: one barrier per exchange.  With one tile a second barrier
+// after the reads protects it.
+template <typename T, bool PP>
+struct TileSel {
+  Cx<T>* base;
+  Cx<T>* cur;
+  int tile;   // elements per tile
+  int phase;
+  __device__ __forceinline__ TileSel(Cx<T>* lds, int tile_elems) : base(lds), cur(lds), tile(tile_elems), phase(0) {}
+  __device__ __forceinline__ Cx<T>* next() {
+    cur = base + ((PP && phase) ? tile : 0);
+    phase ^= 1;
+    return cur;
+  }
+  __device__ __forceinline__ void after_read() {
+    if (!PP) __syncthreads();
+  }
+};
+
+// All stages of one batched FFT, stage S onward.  FIRST_FROM_LDS: stage 0 inputs are read
+// from the tile the caller obtained with sel.next() and filled (the caller must NOT have
+// synchronised) instead of being supplied in v.  On return v[m] holds element u + m L/8 of
+// the transform (the last stage of every plan lands in natural order).
+template <int SIGN, bool FIRST_FROM_LDS, int LG, typename LAY, int S, typename T, bool PP>
+__device__ __forceinline__ void fft_run_from(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u,
+                                             const Twiddles<T, LG>& tw) {
   if constexpr (S < Plan<LG>::NST) {
     if constexpr (S > 0 || FIRST_FROM_LDS) {
       if constexpr (S > 0) {
+        Cx<T>* w = sel.next();
 #pragma unroll
-        for (int m = 0; m < 8; ++m) lds[stage_pos<LG, S - 1>(u, m) * TSP + t] = v[m];
+        for (int m = 0; m < 8; ++m) w[LAY::idx(stage_pos<LG, S - 1>(u, m), t)] = v[m];
       }
       __syncthreads();
+      const Cx<T>* r = sel.cur;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = lds[(u + m * Plan<LG>::L8) * TSP + t];
-      __syncthreads();
+      for (int m = 0; m < 8; ++m) v[m] = r[LAY::idx(u + m * Plan<LG>::L8, t)];
+      sel.after_read();
     }
     butterflies<SIGN, LG, S>(v, tw);
-    fft_run_from<SIGN, FIRST_FROM_LDS, LG, TSP, S + 1>(v, lds, t, u, tw);
+    fft_run_from<SIGN, FIRST_FROM_LDS, LG, LAY, S + 1>(v, sel, t, u, tw);
   }
 }
-template <int SIGN, bool FIRST_FROM_LDS, int LG, int TSP, typename T>
-__device__ __forceinline__ void fft_run(Cx<T> (&v)[8], Cx<T>* lds, int t, int u, const Twiddles<T, LG>& tw) {
-  fft_run_from<SIGN, FIRST_FROM_LDS, LG, TSP, 0>(v, lds, t, u, tw);
+template <int SIGN, bool FIRST_FROM_LDS, int LG, typename LAY, typename T, bool PP>
+__device__ __forceinline__ void fft_run(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u, const Twiddles<T, LG>& tw) {
+  fft_run_from<SIGN, FIRST_FROM_LDS, LG, LAY, 0>(v, sel, t, u, tw);
 }
-template <int LG>
-__device__ __forceinline__ int out_pos(int u, int m) {
-  return stage_pos<LG, Plan<LG>::NST - 1>(u, m);
+
+// w * exp(-i pi m / 8): the zero-padding twiddle exp(-i pi n / L) of element n = u + m L/8 is
+// the per-thread factor exp(-i pi u / L) times this constant, so one table load serves all
+// eight elements of a work item.
+template <typename T>
+__device__ __forceinline__ Cx<T> mul_c16(Cx<T> w, int m) {
+  constexpr double c[8] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
+                           0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613};
+  constexpr double sn[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613,
+                            1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173};
+  if (m == 0) return w;
+  if (m == 4) return Cx<T>{w.y, -w.x};
+  const T cc = (T)c[m], ss = (T)sn[m];
+  return Cx<T>{w.x * cc + w.y * ss, w.y * cc - w.x * ss};
 }
+
+constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 
 // Geometry of the spectral buffers.
 //   bufA (exchange layout) : [rank P][comp nc][z nzl][y ny][KXP]      x_fwd out, x_inv in
@@ -258,19 +307,33 @@ __device__ __forceinline__ size_t rowB(const PGeo& G, int c, int z, int kyp) {
          (size_t)G.KXP;
 }
 
-#define FFT_KERNEL_PROLOGUE(ROWS)                                                  \
-  constexpr int L = Plan<LG>::L, L8 = Plan<LG>::L8;                                \
-  constexpr int TS = tile_seqs(L, sizeof(T) == 4, ROWS), NT = TS * L / 8;          \
-  extern __shared__ char smem[];                                                   \
-  Cx<T>* lds = reinterpret_cast<Cx<T>*>(smem);                                     \
-  const int t = threadIdx.x & (TS - 1), u = threadIdx.x / TS;                      \
-  Twiddles<T, LG> tw;                                                              \
-  load_stage_tw<T, LG, 0>(tw, u, tw4);                                             \
-  (void)L8; (void)NT;
+template <typename T, int LG, bool ROWS>
+struct TileCfg {
+  static constexpr int L = Plan<LG>::L, L8 = Plan<LG>::L8;
+  static constexpr int TS = tile_seqs(L, sizeof(T) == 4, ROWS), NT = TS * L8;
+  static constexpr int PITCH = L + L / 8 + 1;                            // row layout
+  static constexpr int ELEMS = ROWS ? TS * PITCH : L * TS;               // one tile
+  static constexpr bool PP = 2 * ELEMS * sizeof(Cx<T>) <= kLdsBudget;    // room for two tiles
+  static constexpr size_t BYTES = (PP ? 2 : 1) * ELEMS * sizeof(Cx<T>);
+  using Lay = typename std::conditional<ROWS, RowLayout<PITCH>, ColLayout<TS>>::type;
+};
+
+#define FFT_KERNEL_PROLOGUE(ROWS)                                                      \
+  using Cfg = TileCfg<T, LG, ROWS>;                                                    \
+  using Lay = typename Cfg::Lay;                                                       \
+  constexpr int L = Cfg::L, L8 = Cfg::L8, TS = Cfg::TS;                                \
+  extern __shared__ char smem[];                                                       \
+  TileSel<T, Cfg::PP> sel(reinterpret_cast<Cx<T>*>(smem), Cfg::ELEMS);                 \
+  const int t = ROWS ? threadIdx.x / L8 : threadIdx.x & (TS - 1);                      \
+  const int u = ROWS ? threadIdx.x & (L8 - 1) : threadIdx.x / TS;                      \
+  Twiddles<T, LG> tw;                                                                  \
+  load_stage_tw<T, LG, 0>(tw, u, tw4);                                                 \
+  const Cx<T> wu = tw4[2 * u]; /* exp(-i pi u / L) */                                  \
+  (void)L; (void)wu;
 
 // ------------------------------------------------------------------------- y forward
 template <typename T, int LG>
-__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1 << LG) / 8)
+__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
@@ -285,18 +348,18 @@ __global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1
 #pragma unroll
   for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * tw4[2 * (u + m * L8)] : a0[m];
-    fft_run<-1, false, LG, TS>(v, lds, t, u, tw);
+    for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
+    fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
     if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) dst[(size_t)(parity * L + out_pos<LG>(u, m)) * kystride] = v[m];
+      for (int m = 0; m < 8; ++m) dst[(size_t)(parity * L + u + m * L8) * kystride] = v[m];
     }
   }
 }
 
 // ------------------------------------------------------------------------- y inverse
 template <typename T, int LG>
-__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1 << LG) / 8)
+__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
@@ -309,15 +372,14 @@ __global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1
   for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = ok ? src[(size_t)(parity * L + u + m * L8) * kystride] : Cx<T>{0, 0};
-    fft_run<+1, false, LG, TS>(v, lds, t, u, tw);
+    fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
     if (parity == 0) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) res[m] = v[m];
     } else if (ok) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        const int n = out_pos<LG>(u, m);
-        dst[(size_t)n * G.KXP] = res[m] + conj(tw4[2 * n]) * v[m];
+        dst[(size_t)(u + m * L8) * G.KXP] = res[m] + conj(mul_c16(wu, m)) * v[m];
       }
     }
   }
@@ -326,7 +388,7 @@ __global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1
 // ------------------------------------------------------------------------- z convolution
 // forward nz -> 2nz, multiply by the folded Green's table, inverse 2nz -> nz, in place.
 template <typename T, int LG>
-__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1 << LG) / 8)
+__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = blockIdx.z, kyp = blockIdx.y, col = blockIdx.x * TS + t;
@@ -344,26 +406,29 @@ __global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1
 #pragma unroll
   for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * tw4[2 * (u + m * L8)] : a0[m];
-    fft_run<-1, false, LG, TS>(v, lds, t, u, tw);
-    // spectrum at kz = 2 pos + pz, times the Green's table; into the tile in natural order
+    for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * mul_c16(wu, m) : a0[m];
+    // Green's table values for the spectrum at kz = 2 pos + pz: all eight loads are issued
+    // before the transform so that their latency hides behind it
+    T gval[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const int pos = out_pos<LG>(u, m);
-      const int kz = 2 * pos + pz;
+      const int kz = 2 * (u + m * L8) + pz;
       const int kzc = kz <= G.nz ? kz : 2 * G.nz - kz;
-      const T gval = ok ? gbase[(size_t)kzc * gstride] : T(0);
-      lds[pos * TS + t] = scale(v[m], gval);
+      gval[m] = ok ? gbase[(size_t)kzc * gstride] : T(0);
     }
-    fft_run<+1, true, LG, TS>(v, lds, t, u, tw);
+    fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
+    // spectrum times the table, into the tile in natural order
+    Cx<T>* spec = sel.next();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) spec[Lay::idx(u + m * L8, t)] = scale(v[m], gval[m]);
+    fft_run<+1, true, LG, Lay>(v, sel, t, u, tw);
     if (pz == 0) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) res[m] = v[m];
     } else if (ok) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        const int n = out_pos<LG>(u, m);
-        base[zoff(n)] = res[m] + conj(tw4[2 * n]) * v[m];
+        base[zoff(u + m * L8)] = res[m] + conj(mul_c16(wu, m)) * v[m];
       }
     }
   }
@@ -376,130 +441,122 @@ __global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, false) * (1
 //   X[k] = (Z[k] + conj Z[M-k]) / 2 - (i/2) e^{-2 pi i k / 2M} (Z[k] - conj Z[M-k]),  M = nx.
 // Even k only need the even transform, odd k only the odd one.  Output column order:
 // j = 0..L holds kx = 2j, j = L+1..2L holds kx = 2(j-L-1)+1.
+// Lanes run along a row: a work item loads and stores its own eight elements directly
+// (each a 256-byte or longer contiguous run per row), the tile is only used by the
+// transform stages and by the Z[M-k] lookup of the untangle.
 struct FieldGeo {
-  int g, px;
+  int g, px, vec2;  // vec2: rows may be accessed as aligned pairs of reals
   long long plane, vol;
 };
 
+template <typename T>
+__device__ __forceinline__ Cx<T> load_pair(const T* p, bool vec2) {
+  if (vec2) return *reinterpret_cast<const Cx<T>*>(p);
+  return Cx<T>{p[0], p[1]};
+}
+template <typename T>
+__device__ __forceinline__ void store_pair(T* p, Cx<T> a, bool vec2) {
+  if (vec2) {
+    *reinterpret_cast<Cx<T>*>(p) = a;
+  } else {
+    p[0] = a.x;
+    p[1] = a.y;
+  }
+}
+
+// element offset of spectral column j of row (c, zl, y) in the exchange layout
+__device__ __forceinline__ size_t colA(const PGeo& G, size_t rowbase, size_t rank_stride, int j) {
+  if (G.P == 1) return rowbase + j;
+  const int rk = j / G.KXL;
+  return rowbase + rk * rank_stride + (j - rk * G.KXL);
+}
+
 template <typename T, int LG>
-__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, true) * (1 << LG) / 8)
+__global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  constexpr int TSP = TS + 1, NW = NT / 64 > 0 ? NT / 64 : 1;
-  const int c = blockIdx.z, zl = blockIdx.y, y0 = blockIdx.x * TS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* fbase = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + F.g;
-  Cx<T> v[8];
-  for (int parity = 0; parity < 2; ++parity) {
-    for (int r = wave; r < TS; r += NW) {
-      const int y = y0 + r;
-      const T* row = fbase + (size_t)(y + F.g) * F.px;
-      for (int n = lane; n < L; n += 64) {
-        Cx<T> a{0, 0};
-        if (y < G.ny) {
-          a.x = row[2 * n];
-          a.y = row[2 * n + 1];
-        }
-        if (parity) a = a * tw4[2 * n];
-        lds[n * TSP + r] = a;
-      }
-    }
-    fft_run<-1, true, LG, TSP>(v, lds, t, u, tw);
+  const int c = blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
+  const bool ok = y < G.ny;
+  const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
+  const size_t rank_stride = (size_t)G.nc * G.nzl * G.ny * G.KXP;
+  const size_t rowbase = (((size_t)c * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
+  const Cx<T> w1 = tw4[1];  // exp(-i pi / 2L)
+  Cx<T> v[8], a0[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) lds[out_pos<LG>(u, m) * TSP + t] = v[m];
+  for (int m = 0; m < 8; ++m) a0[m] = ok ? load_pair(row + 2 * (u + m * L8), F.vec2) : Cx<T>{0, 0};
+#pragma unroll
+  for (int parity = 0; parity < 2; ++parity) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
+    fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
+    Cx<T>* z = sel.next();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) z[Lay::idx(u + m * L8, t)] = v[m];
     __syncthreads();
-    const int cnt = L + 1 - parity;
-    for (int r = wave; r < TS; r += NW) {
-      const int y = y0 + r;
-      if (y >= G.ny) continue;
-      for (int m = lane; m < cnt; m += 64) {
-        Cx<T> a, b, w;
-        if (parity == 0) {
-          a = lds[(m & (L - 1)) * TSP + r];
-          b = conj(lds[((L - m) & (L - 1)) * TSP + r]);
-          w = tw4[2 * m];
-        } else {
-          a = lds[m * TSP + r];
-          b = conj(lds[(L - 1 - m) * TSP + r]);
-          w = tw4[2 * m + 1];
-        }
-        Cx<T> s = a + b, d = w * (a - b);
-        Cx<T> X{(T)0.5 * (s.x + d.y), (T)0.5 * (s.y - d.x)};  // s/2 - (i/2) d
-        const int j = parity ? L + 1 + m : m;
-        const int rk = j / G.KXL, jl = j - rk * G.KXL;
-        out[((((size_t)rk * G.nc + c) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP + jl] = X;
+    if (ok) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int k = u + m * L8;
+        const int kp = parity ? L - 1 - k : (L - k) & (L - 1);
+        const Cx<T> a = v[m], b = conj(z[Lay::idx(kp, t)]);
+        Cx<T> w = mul_c16(wu, m);  // exp(-i pi k / L)
+        if (parity) w = w * w1;
+        const Cx<T> sm = a + b, d = w * (a - b);
+        const Cx<T> X{(T)0.5 * (sm.x + d.y), (T)0.5 * (sm.y - d.x)};  // s/2 - (i/2) d
+        out[colA(G, rowbase, rank_stride, parity ? L + 1 + k : k)] = X;
+      }
+      if (parity == 0 && u == 0) {
+        // kx = 2L (j = L): X = Re Z[0] - Im Z[0]
+        out[colA(G, rowbase, rank_stride, L)] = Cx<T>{v[0].x - v[0].y, T(0)};
       }
     }
-    __syncthreads();
+    sel.after_read();
   }
 }
 
 // ------------------------------------------------------------------------- x inverse
+// Z[k] = E[k] + i O[k], E = (X[k] + conj X[M-k]) / 2, O = (X[k] - conj X[M-k]) / 2 * e^{+2 pi i k / 2M},
+// formed per work item from its own eight columns and their mirror columns (both read
+// straight from the exchange layout), then the truncated inverse pair of L-point transforms.
 template <typename T, int LG>
-__global__ void __launch_bounds__(tile_seqs(1 << LG, sizeof(T) == 4, true) * (1 << LG) / 8)
+__global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  constexpr int TSP = TS + 1, NW = NT / 64 > 0 ? NT / 64 : 1;
-  const int c = blockIdx.z, zl = blockIdx.y, y0 = blockIdx.x * TS;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* fbase = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + F.g;
+  const int c = blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
+  const bool ok = y < G.ny;
+  T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
+  const size_t rank_stride = (size_t)G.nc * G.nzl * G.ny * G.KXP;
+  const size_t rowbase = (((size_t)c * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
+  const Cx<T> w1 = tw4[1];
   Cx<T> v[8], res[8];
+#pragma unroll
   for (int parity = 0; parity < 2; ++parity) {
-    const int cnt = L + 1 - parity;
-    for (int r = wave; r < TS; r += NW) {
-      const int y = y0 + r;
-      for (int m = lane; m < cnt; m += 64) {
-        Cx<T> a{0, 0};
-        if (y < G.ny) {
-          const int j = parity ? L + 1 + m : m;
-          const int rk = j / G.KXL, jl = j - rk * G.KXL;
-          a = in[((((size_t)rk * G.nc + c) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP + jl];
-        }
-        lds[m * TSP + r] = a;
-      }
+    Cx<T> xa[8], xb[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int k = u + m * L8;
+      const int ja = parity ? L + 1 + k : k;
+      const int jb = parity ? 2 * L - k : L - k;  // mirror column M - kx in the same parity block
+      xa[m] = ok ? in[colA(G, rowbase, rank_stride, ja)] : Cx<T>{0, 0};
+      xb[m] = ok ? in[colA(G, rowbase, rank_stride, jb)] : Cx<T>{0, 0};
     }
-    __syncthreads();
-    // Z[k] = E[k] + i O[k], E = (X[k] + conj X[M-k]) / 2, O = (X[k] - conj X[M-k]) / 2 * e^{+2 pi i k / 2M};
-    // pairs (k, M-k) share their two inputs, so each lane rewrites one pair in place.
-    const int npair = parity ? L / 2 : L / 2 + 1;
-    for (int r = wave; r < TS; r += NW) {
-      for (int m = lane; m < npair; m += 64) {
-        const int m2 = parity ? L - 1 - m : L - m;  // partner index in this parity block
-        Cx<T> xa = lds[m * TSP + r], xb = lds[m2 * TSP + r];
-        const int k1 = parity ? 2 * m + 1 : 2 * m, k2 = parity ? 2 * m2 + 1 : 2 * m2;
-        Cx<T> s1 = xa + conj(xb), d1 = conj(tw4[k1]) * (xa - conj(xb));
-        Cx<T> z1{(T)0.5 * (s1.x - d1.y), (T)0.5 * (s1.y + d1.x)};  // s/2 + (i/2) d
-        lds[m * TSP + r] = z1;
-        if (m2 != m && m2 < L) {
-          Cx<T> s2 = xb + conj(xa), d2 = conj(tw4[k2]) * (xb - conj(xa));
-          Cx<T> z2{(T)0.5 * (s2.x - d2.y), (T)0.5 * (s2.y + d2.x)};
-          lds[m2 * TSP + r] = z2;
-        }
-      }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      Cx<T> w = mul_c16(wu, m);
+      if (parity) w = w * w1;
+      const Cx<T> sm = xa[m] + conj(xb[m]), d = conj(w) * (xa[m] - conj(xb[m]));
+      v[m] = Cx<T>{(T)0.5 * (sm.x - d.y), (T)0.5 * (sm.y + d.x)};  // s/2 + (i/2) d
     }
-    fft_run<+1, true, LG, TSP>(v, lds, t, u, tw);
+    fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
     if (parity == 0) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) res[m] = v[m];
-    } else {
+    } else if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int n = out_pos<LG>(u, m);
-        lds[n * TSP + t] = res[m] + conj(tw4[2 * n]) * v[m];
-      }
-      __syncthreads();
-      for (int r = wave; r < TS; r += NW) {
-        const int y = y0 + r;
-        if (y >= G.ny) continue;
-        T* row = fbase + (size_t)(y + F.g) * F.px;
-        for (int n = lane; n < L; n += 64) {
-          Cx<T> a = lds[n * TSP + r];
-          row[2 * n] = a.x;
-          row[2 * n + 1] = a.y;
-        }
-      }
+      for (int m = 0; m < 8; ++m)
+        store_pair(row + 2 * (u + m * L8), res[m] + conj(mul_c16(wu, m)) * v[m], F.vec2);
     }
   }
 }
@@ -648,8 +705,9 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int nc) {
   // which: 0 = y_fwd, 1 = z_conv, 2 = y_inv
   PGeo G = s->G;
   G.nc = nc;
-  constexpr int L = 1 << LG, TS = tile_seqs(L, sizeof(T) == 4, false), NT = TS * L / 8;
-  const size_t lds_bytes = (size_t)L * TS * sizeof(Cx<T>);
+  using Cfg = TileCfg<T, LG, false>;
+  constexpr int TS = Cfg::TS, NT = Cfg::NT;
+  const size_t lds_bytes = Cfg::BYTES;
   dim3 grid((G.KXL + TS - 1) / TS, which == 1 ? 2 * G.ny : G.nz, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[which == 1 ? 2 : 1];
   if (which == 0) {
@@ -673,9 +731,12 @@ template <typename T, int LG>
 static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int nc, void* field) {
   PGeo G = s->G;
   G.nc = nc;
-  constexpr int L = 1 << LG, TS = tile_seqs(L, sizeof(T) == 4, true), NT = TS * L / 8;
-  const size_t lds_bytes = (size_t)(L + 1) * (TS + 1) * sizeof(Cx<T>);
-  FieldGeo F{c->g, c->px, (long long)c->plane, (long long)c->vol};
+  using Cfg = TileCfg<T, LG, true>;
+  constexpr int TS = Cfg::TS, NT = Cfg::NT;
+  const size_t lds_bytes = Cfg::BYTES;
+  // rows start g reals into a padded row: pairs are aligned when g and the row pitch are even
+  const int vec2 = (c->g % 2 == 0) && (c->px % 2 == 0) && ((uintptr_t)field % (2 * sizeof(T)) == 0);
+  FieldGeo F{c->g, c->px, vec2, (long long)c->plane, (long long)c->vol};
   dim3 grid((G.ny + TS - 1) / TS, G.nzl, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[0];
   if (fwd) {

@@ -116,7 +116,9 @@ __device__ __forceinline__ bool in_ext(int a, int p) { return a >= 1 && a <= p -
 
 // ---------------------------------------------------------------- diffusion flux
 // flux = c * (sum of the six neighbours - 6 f) on D, 0 elsewhere.
-template <typename T, int V>
+// ADD: the output is f + flux instead (every cell written, a copy of f outside D): the whole
+// diffusion timestep in one pass when the result may land in another array than its input.
+template <typename T, int V, bool ADD = false>
 __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux, const T* __restrict__ f, T c,
                                                            Geo G, int zchunk) {
   long long q;
@@ -134,11 +136,12 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
   int z0 = blockIdx.y * zchunk, z1 = min(z0 + zchunk, G.pz);
   int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
   const Pack<T, V> zero = zero_pack<T, V>();
+  auto outside = [&](int z) { st<T, V>(flux + z * G.plane, ADD ? ld<T, V>(f + z * G.plane) : zero); };
   if (!any || zs > ze) {
-    for (int z = z0; z < z1; ++z) st<T, V>(flux + z * G.plane, zero);
+    for (int z = z0; z < z1; ++z) outside(z);
     return;
   }
-  for (int z = z0; z < zs; ++z) st<T, V>(flux + z * G.plane, zero);
+  for (int z = z0; z < zs; ++z) outside(z);
   Pack<T, V> prev = ld<T, V>(f + (zs - 1) * G.plane), cur = ld<T, V>(f + zs * G.plane);
   for (int z = zs; z <= ze; ++z) {
     const T* pc = f + z * G.plane;
@@ -152,12 +155,13 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
       T right = e == V - 1 ? xp : cur.v[e + 1];
       T val = c * (right + left + yp.v[e] + ym.v[e] + nxt.v[e] + prev.v[e] - T(6) * cur.v[e]);
       o.v[e] = core[e] ? val : T(0);
+      if (ADD) o.v[e] = cur.v[e] + o.v[e];
     }
     st<T, V>(flux + z * G.plane, o);
     prev = cur;
     cur = nxt;
   }
-  for (int z = ze + 1; z < z1; ++z) st<T, V>(flux + z * G.plane, zero);
+  for (int z = ze + 1; z < z1; ++z) outside(z);
 }
 
 // ---------------------------------------------------------------- curl / vorticity update
@@ -168,9 +172,11 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
 //   B = { ext(z), face(y), core(x) }                the two y boxes
 //   C = { ext(z), ext(y), face(x) }                 the two x boxes
 // (no band zeroing: update_vorticity_from_velocity_forcing_mpi_3d.py has no PROC_NULL logic).
+// MODE 2: the same update written to another array: out = base + p * curl(f) on U, out = base
+//   elsewhere (every cell of out is written; out must not alias base or f).
 template <typename T, int V, int MODE>
-__global__ void __launch_bounds__(kBlock) k_curl(T* __restrict__ out, const T* __restrict__ f, T pref, Geo G,
-                                                 int zchunk) {
+__global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f, T pref, Geo G, int zchunk,
+                                                 const T* base) {
   long long q;
   int y, x0;
   if (!lane_pos<V>(G, q, y, x0)) return;
@@ -186,7 +192,7 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* __restrict__ out, const T* _
   for (int e = 0; e < V; ++e) {
     bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
     mA[e] = yc && xc;
-    mB[e] = MODE == 1 && ((yf && xc) || (ye && xf));
+    mB[e] = MODE != 0 && ((yf && xc) || (ye && xf));
     any |= mA[e] || mB[e];
   }
   int z0 = blockIdx.y * zchunk, z1 = min(z0 + zchunk, G.pz);
@@ -199,21 +205,22 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* __restrict__ out, const T* _
     ze = min(z1 - 1, G.pz - 2);
   }
   const Pack<T, V> zero = zero_pack<T, V>();
+  // cells this lane does not compute: 0 (MODE 0), untouched (MODE 1), copied from base (MODE 2)
+  const T* bx = MODE == 2 ? base + q : ox;
+  const T* by = MODE == 2 ? base + G.vol + q : oy;
+  const T* bz = MODE == 2 ? base + 2 * G.vol + q : oz;
+  auto outside = [&](int z) {
+    if (MODE == 1) return;
+    const long long zo = z * G.plane;
+    st<T, V>(ox + zo, MODE == 0 ? zero : ld<T, V>(bx + zo));
+    st<T, V>(oy + zo, MODE == 0 ? zero : ld<T, V>(by + zo));
+    st<T, V>(oz + zo, MODE == 0 ? zero : ld<T, V>(bz + zo));
+  };
   if (!any || zs > ze) {
-    if (MODE == 0)
-      for (int z = z0; z < z1; ++z) {
-        st<T, V>(ox + z * G.plane, zero);
-        st<T, V>(oy + z * G.plane, zero);
-        st<T, V>(oz + z * G.plane, zero);
-      }
+    for (int z = z0; z < z1; ++z) outside(z);
     return;
   }
-  if (MODE == 0)
-    for (int z = z0; z < zs; ++z) {
-      st<T, V>(ox + z * G.plane, zero);
-      st<T, V>(oy + z * G.plane, zero);
-      st<T, V>(oz + z * G.plane, zero);
-    }
+  for (int z = z0; z < zs; ++z) outside(z);
   Pack<T, V> fx_prev = ld<T, V>(fx + (zs - 1) * G.plane), fx_cur = ld<T, V>(fx + zs * G.plane);
   Pack<T, V> fy_prev = ld<T, V>(fy + (zs - 1) * G.plane), fy_cur = ld<T, V>(fy + zs * G.plane);
   for (int z = zs; z <= ze; ++z) {
@@ -247,8 +254,8 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* __restrict__ out, const T* _
       st<T, V>(ox + zo, rx);
       st<T, V>(oy + zo, ry);
       st<T, V>(oz + zo, rz);
-    } else if (anym) {
-      Pack<T, V> wx = ld<T, V>(ox + zo), wy = ld<T, V>(oy + zo), wz = ld<T, V>(oz + zo);
+    } else if (anym || MODE == 2) {
+      Pack<T, V> wx = ld<T, V>(bx + zo), wy = ld<T, V>(by + zo), wz = ld<T, V>(bz + zo);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         wx.v[e] = m[e] ? wx.v[e] + rx.v[e] : wx.v[e];
@@ -264,12 +271,7 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* __restrict__ out, const T* _
     fy_prev = fy_cur;
     fy_cur = fy_nxt;
   }
-  if (MODE == 0)
-    for (int z = ze + 1; z < z1; ++z) {
-      st<T, V>(ox + z * G.plane, zero);
-      st<T, V>(oy + z * G.plane, zero);
-      st<T, V>(oz + z * G.plane, zero);
-    }
+  for (int z = ze + 1; z < z1; ++z) outside(z);
 }
 
 // ---------------------------------------------------------------- divergence (diagnostic)
@@ -408,19 +410,40 @@ extern "C" int smi_diffusion_timestep(smi_ctx* c, void* field, void* flux, doubl
   return 0;
 }
 
+// One-pass diffusion timestep into another array: out = in + c * laplacian(in) on D, in elsewhere.
+int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp) {
+  SMI_REQUIRE(out != in, "smi_diffusion_apply: output and input must not alias");
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, in, ncomp));
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, PROF_DIFFUSION_FLUX, 2.0 * ncomp * smi_S(c));
+  SMI_DISPATCH(c, {
+    if (vec_ok<T>(c, out, in)) {
+      LaunchShape s = plan<4>(c, ncomp);
+      k_diffusion_flux<T, 4, true><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, (T)prefactor, G, s.zchunk);
+    } else {
+      LaunchShape s = plan<1>(c, ncomp);
+      k_diffusion_flux<T, 1, true><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, (T)prefactor, G, s.zchunk);
+    }
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int MODE>
-static int run_curl(smi_ctx* c, void* out, void* f, double prefactor) {
-  SMI_REQUIRE(out != f, "curl operators: output and input must not alias");
+static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const void* base = nullptr) {
+  SMI_REQUIRE(out != f && out != base, "curl operators: output and input must not alias");
   if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
   Geo G = make_geo(c);
-  SmiProfScope prof(c, MODE == 1 ? PROF_CURL_UPDATE : PROF_CURL, (MODE == 1 ? 9.0 : 6.0) * smi_S(c));
+  SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
   SMI_DISPATCH(c, {
-    if (vec_ok<T>(c, out, f)) {
+    if (vec_ok<T>(c, out, f) && vec_ok<T>(c, out, base)) {
       LaunchShape s = plan<4>(c, 1);
-      k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
+      k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
+                                                           (const T*)base);
     } else {
       LaunchShape s = plan<1>(c, 1);
-      k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
+      k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
+                                                           (const T*)base);
     }
   });
   SMI_LAUNCH_CHECK();
@@ -431,6 +454,11 @@ extern "C" int smi_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vort
                                                           double prefactor) {
   SMI_REQUIRE(c && vorticity && forcing, "smi_update_vorticity_from_velocity_forcing: bad argument");
   return run_curl<1>(c, vorticity, forcing, prefactor);
+}
+
+// out = vorticity + p * curl(forcing) on the update set, vorticity elsewhere
+int smi_update_vorticity_into_impl(smi_ctx* c, void* out, const void* vorticity, void* forcing, double prefactor) {
+  return run_curl<2>(c, out, forcing, prefactor, vorticity);
 }
 
 extern "C" int smi_curl(smi_ctx* c, void* curl, void* field, double prefactor) {

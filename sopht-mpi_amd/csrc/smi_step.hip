@@ -20,9 +20,12 @@ extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, v
     pref_vel = 0.5 / dx;
   }
   if (forcing) SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, forcing, pref_curl));
-  SMI_CHECK(smi_cross_product(c, buffer_vector, velocity, vorticity));
-  SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, buffer_vector, pref_curl));
-  SMI_CHECK(smi_diffusion_timestep(c, vorticity, buffer_scalar, pref_diff, 3));
+  // Advection and diffusion ping-pong between arrays so each runs as a single pass: the stream
+  // function array (dead until the Poisson solve below rewrites it) holds u x w, the advected
+  // vorticity lands in buffer_vector and the diffusion step brings it back into vorticity.
+  SMI_CHECK(smi_cross_product(c, stream_func, velocity, vorticity));
+  SMI_CHECK(smi_update_vorticity_into_impl(c, buffer_vector, vorticity, stream_func, pref_curl));
+  SMI_CHECK(smi_diffusion_apply_impl(c, vorticity, buffer_vector, pref_diff, 3));
   if (filter_order > 0) {
     size_t stride = c->vol * smi_elem_size(c);
     SMI_CHECK(smi_laplacian_filter(c, vorticity, 3, buffer_vector, (char*)buffer_vector + stride, filter_order,
