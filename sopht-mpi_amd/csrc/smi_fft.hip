@@ -331,20 +331,30 @@ struct TileCfg {
   const Cx<T> wu = tw4[2 * u]; /* exp(-i pi u / L) */                                  \
   (void)L; (void)wu;
 
+// Addressing in the column kernels: every global access is (workgroup-uniform 64-bit
+// pointer that absorbs the element index m) [32-bit per-thread offset].  The per-thread part
+// is computed once; no per-access 64-bit multiplies are left in the vector pipeline.  The
+// create call checks that one (component, tile) slice stays below 2^32 bytes.
+//
+// Tiles of at most 16 columns always lie inside the padded row pitch, so their pad columns
+// are transformed along with the rest (finite garbage that nothing reads) and no lane is
+// predicated off.
+
 // ------------------------------------------------------------------------- y forward
 template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
-  const bool ok = col < G.KXL;
-  const Cx<T>* src = in + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP + col;
-  Cx<T>* dst = out + rowB(G, c, z, 0) + col;
-  const size_t kystride = (size_t)G.KXP << G.zb_shift;
+  const bool ok = TS <= 16 || col < G.KXL;
+  const Cx<T>* src = in + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP;
+  Cx<T>* dst = out + rowB(G, c, z, 0);
+  const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
+  const unsigned off_in = (unsigned)u * G.KXP + col, off_out = (unsigned)u * kystride + col;
   Cx<T> v[8], a0[8];
   // the column is read once and kept in registers for both parities
 #pragma unroll
-  for (int m = 0; m < 8; ++m) a0[m] = ok ? src[(size_t)(u + m * L8) * G.KXP] : Cx<T>{0, 0};
+  for (int m = 0; m < 8; ++m) a0[m] = ok ? (src + (size_t)(m * L8) * G.KXP)[off_in] : Cx<T>{0, 0};
 #pragma unroll
   for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
@@ -352,7 +362,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
     if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) dst[(size_t)(parity * L + u + m * L8) * kystride] = v[m];
+      for (int m = 0; m < 8; ++m) (dst + (size_t)(parity * L + m * L8) * kystride)[off_out] = v[m];
     }
   }
 }
@@ -363,58 +373,68 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
-  const bool ok = col < G.KXL;
-  const Cx<T>* src = in + rowB(G, c, z, 0) + col;
-  const size_t kystride = (size_t)G.KXP << G.zb_shift;
-  Cx<T>* dst = out + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP + col;
+  const bool ok = TS <= 16 || col < G.KXL;
+  const Cx<T>* src = in + rowB(G, c, z, 0);
+  Cx<T>* dst = out + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP;
+  const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
+  const unsigned off_in = (unsigned)u * kystride + col, off_out = (unsigned)u * G.KXP + col;
   Cx<T> v[8], res[8];
 #pragma unroll
   for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = ok ? src[(size_t)(parity * L + u + m * L8) * kystride] : Cx<T>{0, 0};
+    for (int m = 0; m < 8; ++m)
+      v[m] = ok ? (src + (size_t)(parity * L + m * L8) * kystride)[off_in] : Cx<T>{0, 0};
     fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
     if (parity == 0) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) res[m] = v[m];
     } else if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        dst[(size_t)(u + m * L8) * G.KXP] = res[m] + conj(mul_c16(wu, m)) * v[m];
-      }
+      for (int m = 0; m < 8; ++m)
+        (dst + (size_t)(m * L8) * G.KXP)[off_out] = res[m] + conj(mul_c16(wu, m)) * v[m];
     }
   }
 }
 
 // ------------------------------------------------------------------------- z convolution
 // forward nz -> 2nz, multiply by the folded Green's table, inverse 2nz -> nz, in place.
+// Element m of a work item is plane z = u + m L/8.  The z blocks of bufB are at most L/8
+// planes (create enforces it), so z % ZB = u % ZB and z / ZB = u / ZB + m (L/8) / ZB.
+// Its spectrum index kz = 2 z + pz folds to kz for m < 4 and to 2 nz - kz for m >= 4.
 template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = blockIdx.z, kyp = blockIdx.y, col = blockIdx.x * TS + t;
-  const bool ok = col < G.KXL;
-  Cx<T>* base = buf + col;
-  auto zoff = [&](int z) { return rowB(G, c, z, kyp); };
+  const bool ok = TS <= 16 || col < G.KXL;
+  const int ZB = 1 << G.zb_shift;
+  const size_t blk = (size_t)(2 * G.ny) * ZB * G.KXP;  // elements per z block of one component
+  Cx<T>* base = buf + ((size_t)c * (G.nz >> G.zb_shift) * (2 * G.ny) + kyp) * ZB * (size_t)G.KXP;
+  const size_t mstep = (size_t)(L8 >> G.zb_shift) * blk;
+  const unsigned off = (unsigned)(u >> G.zb_shift) * (unsigned)blk + (unsigned)(u & (ZB - 1)) * G.KXP + col;
   const int ky = 2 * (kyp % G.ny) + kyp / G.ny;
   const int kyc = ky <= G.ny ? ky : 2 * G.ny - ky;
-  const T* gbase = green + (size_t)kyc * (G.nz + 1) * G.KXP + col;  // all kz of this ky are contiguous rows
-  const size_t gstride = (size_t)G.KXP;
+  const T* gbase = green + (size_t)kyc * (G.nz + 1) * G.KXP;  // all kz of this ky are contiguous rows
   Cx<T> v[8], res[8], a0[8];
   // the column is read once and kept in registers for both parities
 #pragma unroll
-  for (int m = 0; m < 8; ++m) a0[m] = ok ? base[zoff(u + m * L8)] : Cx<T>{0, 0};
+  for (int m = 0; m < 8; ++m) a0[m] = ok ? (base + m * mstep)[off] : Cx<T>{0, 0};
 #pragma unroll
   for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * mul_c16(wu, m) : a0[m];
-    // Green's table values for the spectrum at kz = 2 pos + pz: all eight loads are issued
+    // Green's table values for the spectrum at kz = 2 z + pz: all eight loads are issued
     // before the transform so that their latency hides behind it
     T gval[8];
+    const unsigned goff_lo = (unsigned)(2 * u + pz) * G.KXP + col;                  // rows kz
+    const unsigned goff_hi = (unsigned)(2 * (L8 - 1 - u) + 1 - pz) * G.KXP + col;   // rows 2 nz - kz
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const int kz = 2 * (u + m * L8) + pz;
-      const int kzc = kz <= G.nz ? kz : 2 * G.nz - kz;
-      gval[m] = ok ? gbase[(size_t)kzc * gstride] : T(0);
+      // m < 4: row 2 m L/8 + (2u + pz).  m >= 4: row 2 nz - 2 m L/8 - (2u + pz), split as
+      // (2 nz - 2 m L/8 - 2 L/8 + 1) + (2 (L/8 - 1 - u) + 1 - pz) so that both parts are >= 0.
+      const T* gm = m < 4 ? gbase + (size_t)(2 * m * L8) * G.KXP
+                          : gbase + (size_t)(2 * L - 2 * m * L8 - 2 * L8 + 1) * G.KXP;
+      gval[m] = ok ? gm[m < 4 ? goff_lo : goff_hi] : T(0);
     }
     fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
     // spectrum times the table, into the tile in natural order
@@ -427,9 +447,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
       for (int m = 0; m < 8; ++m) res[m] = v[m];
     } else if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        base[zoff(u + m * L8)] = res[m] + conj(mul_c16(wu, m)) * v[m];
-      }
+      for (int m = 0; m < 8; ++m) (base + m * mstep)[off] = res[m] + conj(mul_c16(wu, m)) * v[m];
     }
   }
 }
@@ -654,13 +672,18 @@ int smi_pruned_create(smi_poisson* p) {
   G.nc = 3;
   G.KXL = (G.nx + 1 + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
-  G.zb_shift = G.nz >= 16 ? 4 : ilog2(G.nz);
+  // z blocks of at most 16 planes and at most nz / 8 (one work item's elements share z % ZB)
+  G.zb_shift = G.nz >= 128 ? 4 : ilog2(G.nz) - 3;
   s->lgx = ilog2(G.nx / 2);
   s->lgy = ilog2(G.ny);
   s->lgz = ilog2(G.nz);
   const size_t cs = 2 * smi_elem_size(c);
   const size_t nA = (size_t)G.P * G.nc * G.nzl * G.ny * G.KXP;
   const size_t nB = (size_t)G.nc * G.nz * 2 * G.ny * G.KXP;
+  // the kernels address one component slice with 32-bit element offsets scaled by the load
+  SMI_REQUIRE((nA / G.P / G.nc) * cs < (1ull << 32) && (size_t)G.nz * 2 * G.ny * G.KXP / 8 * cs < (1ull << 32) &&
+                  (size_t)(G.nz + 1) * G.KXP * smi_elem_size(c) < (1ull << 32),
+              "SMI_POISSON_PRUNED: grid too large for 32-bit tile offsets");
   SMI_CHECK_HIP(hipMalloc(&s->bufA, nA * cs));
   SMI_CHECK_HIP(hipMemsetAsync(s->bufA, 0, nA * cs, c->stream));
   if (G.P > 1) {

@@ -47,10 +47,10 @@ struct LaunchShape {
   int zchunk;
 };
 
-template <int V>
+template <int V, int BLOCK = kBlock>
 LaunchShape plan(const smi_ctx* c, int ncomp) {
   long long lanes = ((long long)c->plane + V - 1) / V;
-  int bx = (int)((lanes + kBlock - 1) / kBlock);
+  int bx = (int)((lanes + BLOCK - 1) / BLOCK);
   // aim for >= 2048 workgroups while keeping z chunks long enough to amortise the two
   // halo planes each chunk re-reads
   int zchunk = (int)((long long)c->pz * bx * ncomp / 2048);
@@ -100,10 +100,35 @@ __device__ __forceinline__ Pack<T, V> zero_pack() {
   return r;
 }
 
+// Logical block index of this workgroup.  Workgroups are handed to the eight XCDs round
+// robin in launch order, and each XCD has its own L2; the stencil halos (rows y+-1, the two
+// planes at the ends of a z chunk) belong to the neighbouring blocks.  Giving every XCD one
+// contiguous range of the launch-order index keeps those neighbours behind the same L2.
+// It pays for the fused advection kernel (six input fields with halos); the lighter kernels
+// measured marginally faster in plain launch order.
+struct Blk {
+  int x, y, z;
+};
+template <bool REMAP>
+__device__ __forceinline__ Blk xcd_block() {
+  if (!REMAP) return Blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  constexpr unsigned kXcd = 8;
+  const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+  const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  const unsigned xcd = lin % kXcd, idx = lin / kXcd, per = total / kXcd, rem = total % kXcd;
+  const unsigned log = xcd * per + min(xcd, rem) + idx;
+  Blk b;
+  b.x = (int)(log % nx);
+  const unsigned r = log / nx;
+  b.y = (int)(r % ny);
+  b.z = (int)(r / ny);
+  return b;
+}
+
 // flat plane offset of this lane, its row and first column; false when past the plane
 template <int V>
-__device__ __forceinline__ bool lane_pos(const Geo& G, long long& q, int& y, int& x0) {
-  q = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+__device__ __forceinline__ bool lane_pos(const Geo& G, const Blk& B, long long& q, int& y, int& x0) {
+  q = ((long long)B.x * blockDim.x + threadIdx.x) * V;
   if (q >= G.plane) return false;
   y = (int)(q / G.px);
   x0 = (int)(q - (long long)y * G.px);
@@ -123,9 +148,10 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
                                                            Geo G, int zchunk) {
   long long q;
   int y, x0;
-  if (!lane_pos<V>(G, q, y, x0)) return;
-  flux += (long long)blockIdx.z * G.vol + q;
-  f += (long long)blockIdx.z * G.vol + q;
+  const Blk B = xcd_block<false>();
+  if (!lane_pos<V>(G, B, q, y, x0)) return;
+  flux += (long long)B.z * G.vol + q;
+  f += (long long)B.z * G.vol + q;
   bool core[V], any = false;
   bool ycore = in_core(y, G.py, G.g);
 #pragma unroll
@@ -133,7 +159,7 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
     core[e] = ycore && in_core(x0 + e, G.px, G.g);
     any |= core[e];
   }
-  int z0 = blockIdx.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
   int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
   const Pack<T, V> zero = zero_pack<T, V>();
   auto outside = [&](int z) { st<T, V>(flux + z * G.plane, ADD ? ld<T, V>(f + z * G.plane) : zero); };
@@ -179,7 +205,8 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
                                                  const T* base) {
   long long q;
   int y, x0;
-  if (!lane_pos<V>(G, q, y, x0)) return;
+  const Blk B = xcd_block<false>();
+  if (!lane_pos<V>(G, B, q, y, x0)) return;
   const T* fx = f + q;
   const T* fy = f + G.vol + q;
   const T* fz = f + 2 * G.vol + q;
@@ -195,7 +222,7 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
     mB[e] = MODE != 0 && ((yf && xc) || (ye && xf));
     any |= mA[e] || mB[e];
   }
-  int z0 = blockIdx.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
   int zs, ze;
   if (MODE == 0) {
     zs = max(z0, G.zlo_c);
@@ -272,6 +299,140 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
     fy_cur = fy_nxt;
   }
   for (int z = ze + 1; z < z1; ++z) outside(z);
+}
+
+// ---------------------------------------------------------------- fused advection update
+// out = w + p * curl(u x w) on U (the update set of MODE 1 above), out = w elsewhere: the
+// cross product kernel followed by the vorticity update, without the round trip of u x w
+// through HBM.  b = u x w is formed in registers wherever the curl stencil needs it: the
+// plane ahead (kept in the z window as it becomes the centre and then the plane behind),
+// the rows y-1 / y+1 and the two cells left and right of the lane's vector.
+template <typename T, int V>
+struct Vec3 {
+  Pack<T, V> x, y, z;
+};
+template <typename T, int V>
+__device__ __forceinline__ Vec3<T, V> ld3(const T* p, long long vol) {
+  return {ld<T, V>(p), ld<T, V>(p + vol), ld<T, V>(p + 2 * vol)};
+}
+
+constexpr int kAdvectBlock = 256;  // larger blocks (fewer y halo rows per tile) measured slower
+template <typename T, int V>
+__global__ void __launch_bounds__(kAdvectBlock) k_advect(T* __restrict__ out, const T* __restrict__ vel,
+                                                  const T* __restrict__ vort, T pref, Geo G, int zchunk) {
+  long long q;
+  int y, x0;
+  const Blk B = xcd_block<true>();
+  if (!lane_pos<V>(G, B, q, y, x0)) return;
+  const T* u = vel + q;
+  const T* w = vort + q;
+  T* o = out + q;
+  bool mA[V], mB[V], any = false;
+  const bool yc = in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
+    mA[e] = yc && xc;
+    mB[e] = (yf && xc) || (ye && xf);
+    any |= mA[e] || mB[e];
+  }
+  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  const int zs = max(z0, 1), ze = min(z1 - 1, G.pz - 2);
+  auto copy_plane = [&](int z) {
+    const long long zo = z * G.plane;
+    st<T, V>(o + zo, ld<T, V>(w + zo));
+    st<T, V>(o + G.vol + zo, ld<T, V>(w + G.vol + zo));
+    st<T, V>(o + 2 * G.vol + zo, ld<T, V>(w + 2 * G.vol + zo));
+  };
+  if (!any || zs > ze) {
+    for (int z = z0; z < z1; ++z) copy_plane(z);
+    return;
+  }
+  for (int z = z0; z < zs; ++z) copy_plane(z);
+  // z window: b_x, b_y behind; b_y, b_z, w at the centre; everything ahead
+  Pack<T, V> bx_p, by_p, bx_c, by_c, bz_c;
+  Vec3<T, V> w_c;
+  {
+    Vec3<T, V> up = ld3<T, V>(u + (zs - 1) * G.plane, G.vol), wp = ld3<T, V>(w + (zs - 1) * G.plane, G.vol);
+    Vec3<T, V> uc = ld3<T, V>(u + zs * G.plane, G.vol);
+    w_c = ld3<T, V>(w + zs * G.plane, G.vol);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      bx_p.v[e] = up.y.v[e] * wp.z.v[e] - up.z.v[e] * wp.y.v[e];
+      by_p.v[e] = up.z.v[e] * wp.x.v[e] - up.x.v[e] * wp.z.v[e];
+      bx_c.v[e] = uc.y.v[e] * w_c.z.v[e] - uc.z.v[e] * w_c.y.v[e];
+      by_c.v[e] = uc.z.v[e] * w_c.x.v[e] - uc.x.v[e] * w_c.z.v[e];
+      bz_c.v[e] = uc.x.v[e] * w_c.y.v[e] - uc.y.v[e] * w_c.x.v[e];
+    }
+  }
+  for (int z = zs; z <= ze; ++z) {
+    const long long zo = z * G.plane;
+    // plane ahead
+    Vec3<T, V> un = ld3<T, V>(u + zo + G.plane, G.vol), w_n = ld3<T, V>(w + zo + G.plane, G.vol);
+    Pack<T, V> bx_n, by_n, bz_n;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      bx_n.v[e] = un.y.v[e] * w_n.z.v[e] - un.z.v[e] * w_n.y.v[e];
+      by_n.v[e] = un.z.v[e] * w_n.x.v[e] - un.x.v[e] * w_n.z.v[e];
+      bz_n.v[e] = un.x.v[e] * w_n.y.v[e] - un.y.v[e] * w_n.x.v[e];
+    }
+    // rows y-1, y+1: b_x and b_z
+    Pack<T, V> bx_ym, bz_ym, bx_yp, bz_yp;
+    {
+      Vec3<T, V> a = ld3<T, V>(u + zo - G.px, G.vol), b = ld3<T, V>(w + zo - G.px, G.vol);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        bx_ym.v[e] = a.y.v[e] * b.z.v[e] - a.z.v[e] * b.y.v[e];
+        bz_ym.v[e] = a.x.v[e] * b.y.v[e] - a.y.v[e] * b.x.v[e];
+      }
+    }
+    {
+      Vec3<T, V> a = ld3<T, V>(u + zo + G.px, G.vol), b = ld3<T, V>(w + zo + G.px, G.vol);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        bx_yp.v[e] = a.y.v[e] * b.z.v[e] - a.z.v[e] * b.y.v[e];
+        bz_yp.v[e] = a.x.v[e] * b.y.v[e] - a.y.v[e] * b.x.v[e];
+      }
+    }
+    // cells x0-1 and x0+V: b_y and b_z
+    T by_xm, bz_xm, by_xp, bz_xp;
+    {
+      const T* ul = u + zo - 1;
+      const T* wl = w + zo - 1;
+      T ax = ul[0], ay = ul[G.vol], az = ul[2 * G.vol], cx = wl[0], cy = wl[G.vol], cz = wl[2 * G.vol];
+      by_xm = az * cx - ax * cz;
+      bz_xm = ax * cy - ay * cx;
+      const T* ur = u + zo + V;
+      const T* wr = w + zo + V;
+      ax = ur[0], ay = ur[G.vol], az = ur[2 * G.vol], cx = wr[0], cy = wr[G.vol], cz = wr[2 * G.vol];
+      by_xp = az * cx - ax * cz;
+      bz_xp = ax * cy - ay * cx;
+    }
+    const bool zA = z >= G.g && z <= G.pz - G.g - 1;
+    Pack<T, V> rx, ry, rz;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const T byL = e == 0 ? by_xm : by_c.v[e - 1], byR = e == V - 1 ? by_xp : by_c.v[e + 1];
+      const T bzL = e == 0 ? bz_xm : bz_c.v[e - 1], bzR = e == V - 1 ? bz_xp : bz_c.v[e + 1];
+      const bool m = mB[e] || (mA[e] && zA);
+      const T cx = pref * (bz_yp.v[e] - bz_ym.v[e] - by_n.v[e] + by_p.v[e]);
+      const T cy = pref * (bx_n.v[e] - bx_p.v[e] - bzR + bzL);
+      const T cz = pref * (byR - byL - bx_yp.v[e] + bx_ym.v[e]);
+      rx.v[e] = m ? w_c.x.v[e] + cx : w_c.x.v[e];
+      ry.v[e] = m ? w_c.y.v[e] + cy : w_c.y.v[e];
+      rz.v[e] = m ? w_c.z.v[e] + cz : w_c.z.v[e];
+    }
+    st<T, V>(o + zo, rx);
+    st<T, V>(o + G.vol + zo, ry);
+    st<T, V>(o + 2 * G.vol + zo, rz);
+    bx_p = bx_c;
+    by_p = by_c;
+    bx_c = bx_n;
+    by_c = by_n;
+    bz_c = bz_n;
+    w_c = w_n;
+  }
+  for (int z = ze + 1; z < z1; ++z) copy_plane(z);
 }
 
 // ---------------------------------------------------------------- divergence (diagnostic)
@@ -459,6 +620,31 @@ extern "C" int smi_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vort
 // out = vorticity + p * curl(forcing) on the update set, vorticity elsewhere
 int smi_update_vorticity_into_impl(smi_ctx* c, void* out, const void* vorticity, void* forcing, double prefactor) {
   return run_curl<2>(c, out, forcing, prefactor, vorticity);
+}
+
+// out = vorticity + p * curl(velocity x vorticity) on the update set, vorticity elsewhere
+int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor) {
+  SMI_REQUIRE(out != velocity && out != vorticity, "advection update: output and input must not alias");
+  if (smi_multi_rank(c)) {
+    // the ghost planes of u x w are the cross product of the exchanged ghost planes
+    SMI_CHECK(smi_halo_exchange_impl(c, velocity, 3));
+    SMI_CHECK(smi_halo_exchange_impl(c, vorticity, 3));
+  }
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, PROF_CURL_UPDATE, 9.0 * smi_S(c));
+  SMI_DISPATCH(c, {
+    if (vec_ok<T>(c, out, velocity) && vec_ok<T>(c, out, vorticity)) {
+      LaunchShape s = plan<4, kAdvectBlock>(c, 1);
+      k_advect<T, 4><<<s.grid, kAdvectBlock, 0, c->stream>>>((T*)out, (const T*)velocity, (const T*)vorticity,
+                                                       (T)prefactor, G, s.zchunk);
+    } else {
+      LaunchShape s = plan<1, kAdvectBlock>(c, 1);
+      k_advect<T, 1><<<s.grid, kAdvectBlock, 0, c->stream>>>((T*)out, (const T*)velocity, (const T*)vorticity,
+                                                       (T)prefactor, G, s.zchunk);
+    }
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int smi_curl(smi_ctx* c, void* curl, void* field, double prefactor) {

@@ -20,11 +20,10 @@ extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, v
     pref_vel = 0.5 / dx;
   }
   if (forcing) SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, forcing, pref_curl));
-  // Advection and diffusion ping-pong between arrays so each runs as a single pass: the stream
-  // function array (dead until the Poisson solve below rewrites it) holds u x w, the advected
-  // vorticity lands in buffer_vector and the diffusion step brings it back into vorticity.
-  SMI_CHECK(smi_cross_product(c, stream_func, velocity, vorticity));
-  SMI_CHECK(smi_update_vorticity_into_impl(c, buffer_vector, vorticity, stream_func, pref_curl));
+  // Advection and diffusion ping-pong between arrays so each runs as a single pass: the
+  // advected vorticity w + dt/(2dx) curl(u x w) lands in buffer_vector (u x w itself only ever
+  // exists in registers) and the diffusion step brings it back into vorticity.
+  SMI_CHECK(smi_advect_vorticity_impl(c, buffer_vector, velocity, vorticity, pref_curl));
   SMI_CHECK(smi_diffusion_apply_impl(c, vorticity, buffer_vector, pref_diff, 3));
   if (filter_order > 0) {
     size_t stride = c->vol * smi_elem_size(c);
