@@ -213,11 +213,11 @@ constexpr int tile_seqs(int L, bool f32, bool rows) {
 // the autosort stages over the banks.
 template <int TSP>
 struct ColLayout {
-  static __device__ __forceinline__ int idx(int pos, int t) { return pos * TSP + t; }
+  static constexpr __host__ __device__ __forceinline__ int idx(int pos, int t) { return pos * TSP + t; }
 };
 template <int PITCH>
 struct RowLayout {
-  static __device__ __forceinline__ int idx(int pos, int t) { return t * PITCH + pos + (pos >> 3); }
+  static constexpr __host__ __device__ __forceinline__ int idx(int pos, int t) { return t * PITCH + pos + (pos >> 3); }
 };
 
 // Hands out the tile for the next exchange.  With two tiles (PP) consecutive exchanges
@@ -401,54 +401,75 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
 // Element m of a work item is plane z = u + m L/8.  The z blocks of bufB are at most L/8
 // planes (create enforces it), so z % ZB = u % ZB and z / ZB = u / ZB + m (L/8) / ZB.
 // Its spectrum index kz = 2 z + pz folds to kz for m < 4 and to 2 nz - kz for m >= 4.
+//
+// One workgroup owns a column tile and one folded ky index: it walks over the (at most two)
+// ky' rows that fold onto it and over the components, up to six tiles that all use the same
+// rows of the Green's table (read from HBM once, from cache afterwards).  The next tile's
+// column is requested as soon as the registers of the current one are free (after the odd
+// parity pre-twiddle), so its latency hides behind the second half of the arithmetic.
 template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
-  const int c = blockIdx.z, kyp = blockIdx.y, col = blockIdx.x * TS + t;
+  const int kyc = blockIdx.y, col = blockIdx.x * TS + t;
   const bool ok = TS <= 16 || col < G.KXL;
   const int ZB = 1 << G.zb_shift;
   const size_t blk = (size_t)(2 * G.ny) * ZB * G.KXP;  // elements per z block of one component
-  Cx<T>* base = buf + ((size_t)c * (G.nz >> G.zb_shift) * (2 * G.ny) + kyp) * ZB * (size_t)G.KXP;
+  const size_t cstride = (size_t)(G.nz >> G.zb_shift) * blk;
   const size_t mstep = (size_t)(L8 >> G.zb_shift) * blk;
   const unsigned off = (unsigned)(u >> G.zb_shift) * (unsigned)blk + (unsigned)(u & (ZB - 1)) * G.KXP + col;
-  const int ky = 2 * (kyp % G.ny) + kyp / G.ny;
-  const int kyc = ky <= G.ny ? ky : 2 * G.ny - ky;
+  // ky' rows folding onto kyc: ky = kyc and ky = 2 ny - kyc (the same row for kyc = 0 and ny)
+  const int nk = (kyc == 0 || kyc == G.ny) ? 1 : 2;
+  const int ntile = nk * G.nc;
+  auto tile_base = [&](int it) {
+    const int ky = it < G.nc ? kyc : 2 * G.ny - kyc;
+    const int c = it < G.nc ? it : it - G.nc;
+    const int kyp = (ky & 1) * G.ny + (ky >> 1);
+    return buf + (size_t)c * cstride + (size_t)kyp * ZB * G.KXP;
+  };
   const T* gbase = green + (size_t)kyc * (G.nz + 1) * G.KXP;  // all kz of this ky are contiguous rows
   Cx<T> v[8], res[8], a0[8];
-  // the column is read once and kept in registers for both parities
+  Cx<T>* base = tile_base(0);
 #pragma unroll
   for (int m = 0; m < 8; ++m) a0[m] = ok ? (base + m * mstep)[off] : Cx<T>{0, 0};
+  for (int it = 0; it < ntile; ++it) {
+    Cx<T>* next = tile_base(it + 1 < ntile ? it + 1 : it);
 #pragma unroll
-  for (int pz = 0; pz < 2; ++pz) {
+    for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * mul_c16(wu, m) : a0[m];
-    // Green's table values for the spectrum at kz = 2 z + pz: all eight loads are issued
-    // before the transform so that their latency hides behind it
-    T gval[8];
-    const unsigned goff_lo = (unsigned)(2 * u + pz) * G.KXP + col;                  // rows kz
-    const unsigned goff_hi = (unsigned)(2 * (L8 - 1 - u) + 1 - pz) * G.KXP + col;   // rows 2 nz - kz
+      for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * mul_c16(wu, m) : a0[m];
+      if (pz == 1 && it + 1 < ntile) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      // m < 4: row 2 m L/8 + (2u + pz).  m >= 4: row 2 nz - 2 m L/8 - (2u + pz), split as
-      // (2 nz - 2 m L/8 - 2 L/8 + 1) + (2 (L/8 - 1 - u) + 1 - pz) so that both parts are >= 0.
-      const T* gm = m < 4 ? gbase + (size_t)(2 * m * L8) * G.KXP
-                          : gbase + (size_t)(2 * L - 2 * m * L8 - 2 * L8 + 1) * G.KXP;
-      gval[m] = ok ? gm[m < 4 ? goff_lo : goff_hi] : T(0);
+        for (int m = 0; m < 8; ++m) a0[m] = ok ? (next + m * mstep)[off] : Cx<T>{0, 0};
+      }
+      // Green's table values for the spectrum at kz = 2 z + pz: all eight loads are issued
+      // before the transform so that their latency hides behind it
+      T gval[8];
+      const unsigned goff_lo = (unsigned)(2 * u + pz) * G.KXP + col;                 // rows kz
+      const unsigned goff_hi = (unsigned)(2 * (L8 - 1 - u) + 1 - pz) * G.KXP + col;  // rows 2 nz - kz
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        // m < 4: row 2 m L/8 + (2u + pz).  m >= 4: row 2 nz - 2 m L/8 - (2u + pz), split as
+        // (2 nz - 2 m L/8 - 2 L/8 + 1) + (2 (L/8 - 1 - u) + 1 - pz) so that both parts are >= 0.
+        const T* gm = m < 4 ? gbase + (size_t)(2 * m * L8) * G.KXP
+                            : gbase + (size_t)(2 * L - 2 * m * L8 - 2 * L8 + 1) * G.KXP;
+        gval[m] = ok ? gm[m < 4 ? goff_lo : goff_hi] : T(0);
+      }
+      fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
+      // the transform leaves element u + m L/8 in v[m], which is exactly what the first stage
+      // of the inverse wants from this work item: scale in registers and go straight on
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = scale(v[m], gval[m]);
+      fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
+      if (pz == 0) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) res[m] = v[m];
+      } else if (ok) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) (base + m * mstep)[off] = res[m] + conj(mul_c16(wu, m)) * v[m];
+      }
     }
-    fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
-    // spectrum times the table, into the tile in natural order
-    Cx<T>* spec = sel.next();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) spec[Lay::idx(u + m * L8, t)] = scale(v[m], gval[m]);
-    fft_run<+1, true, LG, Lay>(v, sel, t, u, tw);
-    if (pz == 0) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) res[m] = v[m];
-    } else if (ok) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) (base + m * mstep)[off] = res[m] + conj(mul_c16(wu, m)) * v[m];
-    }
+    base = next;
   }
 }
 
@@ -731,7 +752,8 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int nc) {
   using Cfg = TileCfg<T, LG, false>;
   constexpr int TS = Cfg::TS, NT = Cfg::NT;
   const size_t lds_bytes = Cfg::BYTES;
-  dim3 grid((G.KXL + TS - 1) / TS, which == 1 ? 2 * G.ny : G.nz, nc);
+  // z_conv: one workgroup per (column tile, folded ky), looping over mirror rows and components
+  dim3 grid((G.KXL + TS - 1) / TS, which == 1 ? G.ny + 1 : G.nz, which == 1 ? 1 : nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[which == 1 ? 2 : 1];
   if (which == 0) {
     SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG>, lds_bytes));
