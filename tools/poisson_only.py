@@ -2,7 +2,7 @@
 in-library per-kernel event timings printed at the end."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "sopht-mpi_amd")]
 from sopht_mpi_amd import _lib
 from sopht_mpi_amd.numeric.eulerian_grid_ops import UnboundedPoissonSolverMPI3D
