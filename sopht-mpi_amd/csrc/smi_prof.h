@@ -31,6 +31,7 @@ enum SmiProfSlot {
   PROF_IB_SPREAD,
   PROF_FUSED_ADVECT,
   PROF_FUSED_DIFFUSE,
+  PROF_ADVECTION,
   PROF_NUM_SLOTS
 };
 

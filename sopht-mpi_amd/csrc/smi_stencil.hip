@@ -435,6 +435,53 @@ __global__ void __launch_bounds__(kAdvectBlock) k_advect(T* __restrict__ out, co
   for (int z = ze + 1; z < z1; ++z) copy_plane(z);
 }
 
+// ---------------------------------------------------------------- conservative advection flux
+// flux = c * sum over axes of (F(i+1/2) - F(i-1/2)) on W, 0 elsewhere, with the face flux
+//   F(i+1/2) = v_f * (v_f > 0 ? (-f[i-1] + 5 f[i] + 2 f[i+1]) / 6 : (2 f[i] + 5 f[i+1] - f[i+2]) / 6),
+//   v_f = (v[i] + v[i+1]) / 2
+// (third-order upwind-biased reconstruction, kernel support 2; the body of the reference's
+// ENO3 flux lives in a package that is not part of its tree, so this follows the CPU
+// restatement it is tested against).  W is what the seven boxes of advection_flux_mpi_3d.py
+// :39-193 cover once two layers are taken off each: with core(a) = a in [g+2, p-g-3],
+// face(a) = a in [g, g+1] or [p-g-2, p-g-1], ext(a) = a in [2, p-3]:
+//   W = { z in [g, pz-g-1], core(y), core(x) } + { ext(z), face(y), core(x) } + { ext(z), ext(y), face(x) }.
+template <typename T>
+__device__ __forceinline__ T upwind3_face(const T* f, const T* v, long long stride) {
+  // face between the cell at f / v and the next one along stride
+  const T vf = T(0.5) * (v[0] + v[stride]);
+  const T left = T(-1.0 / 6) * f[-stride] + T(5.0 / 6) * f[0] + T(1.0 / 3) * f[stride];
+  const T right = T(1.0 / 3) * f[0] + T(5.0 / 6) * f[stride] + T(-1.0 / 6) * f[2 * stride];
+  return vf * (vf > T(0) ? left : right);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_advection_flux(T* __restrict__ flux, const T* __restrict__ f,
+                                                          const T* __restrict__ vel, T c, Geo G) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.vol) return;
+  const int z = (int)(i / G.plane);
+  const long long r = i - (long long)z * G.plane;
+  const int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
+  auto core = [&](int a, int p) { return a >= G.g + 2 && a <= p - G.g - 3; };
+  auto face = [&](int a, int p) { return (a >= G.g && a <= G.g + 1) || (a >= p - G.g - 2 && a <= p - G.g - 1); };
+  auto ext = [&](int a, int p) { return a >= 2 && a <= p - 3; };
+  const bool in_w = (z >= G.g && z <= G.pz - G.g - 1 && core(y, G.py) && core(x, G.px)) ||
+                    (ext(z, G.pz) && face(y, G.py) && core(x, G.px)) ||
+                    (ext(z, G.pz) && ext(y, G.py) && face(x, G.px));
+  T val = T(0);
+  if (in_w) {
+    const T* fc = f + i;
+    const T* vx = vel + i;
+    const T* vy = vel + G.vol + i;
+    const T* vz = vel + 2 * G.vol + i;
+    const T dx = upwind3_face(fc, vx, 1) - upwind3_face(fc - 1, vx - 1, 1);
+    const T dy = upwind3_face(fc, vy, (long long)G.px) - upwind3_face(fc - G.px, vy - G.px, (long long)G.px);
+    const T dz = upwind3_face(fc, vz, G.plane) - upwind3_face(fc - G.plane, vz - G.plane, G.plane);
+    val = c * (dx + dy + dz);
+  }
+  flux[i] = val;
+}
+
 // ---------------------------------------------------------------- divergence (diagnostic)
 // div = (0.5 * inv_dx) * (dfx/dx + dfy/dy + dfz/dz central differences) on D, 0 elsewhere.
 template <typename T>
@@ -576,7 +623,7 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
   SMI_REQUIRE(out != in, "smi_diffusion_apply: output and input must not alias");
   if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, in, ncomp));
   Geo G = make_geo(c);
-  SmiProfScope prof(c, PROF_DIFFUSION_FLUX, 2.0 * ncomp * smi_S(c));
+  SmiProfScope prof(c, PROF_FUSED_DIFFUSE, 2.0 * ncomp * smi_S(c));
   SMI_DISPATCH(c, {
     if (vec_ok<T>(c, out, in)) {
       LaunchShape s = plan<4>(c, ncomp);
@@ -631,7 +678,7 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
     SMI_CHECK(smi_halo_exchange_impl(c, vorticity, 3));
   }
   Geo G = make_geo(c);
-  SmiProfScope prof(c, PROF_CURL_UPDATE, 9.0 * smi_S(c));
+  SmiProfScope prof(c, PROF_FUSED_ADVECT, 9.0 * smi_S(c));
   SMI_DISPATCH(c, {
     if (vec_ok<T>(c, out, velocity) && vec_ok<T>(c, out, vorticity)) {
       LaunchShape s = plan<4, kAdvectBlock>(c, 1);
@@ -768,8 +815,23 @@ extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* fi
 
 extern "C" int smi_advection_timestep_eno3(smi_ctx* c, void* field, void* flux, void* velocity, double dt_by_dx,
                                            int ncomp) {
-  (void)c; (void)field; (void)flux; (void)velocity; (void)dt_by_dx; (void)ncomp;
-  smi_set_error("smi_advection_timestep_eno3: the ENO3 flux body lives in the un-vendored sopht package and is "
-                "not implemented on the GPU yet (3D Navier-Stokes does not use it)");
-  return 2;
+  SMI_REQUIRE(c && field && flux && velocity && ncomp >= 1, "smi_advection_timestep_eno3: bad argument");
+  SMI_REQUIRE(flux != field && flux != velocity, "smi_advection_timestep_eno3: flux must not alias its inputs");
+  SMI_REQUIRE(c->g >= 2, "smi_advection_timestep_eno3: kernel support 2 needs ghost_size >= 2 (got %d)", c->g);
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, velocity, 3));
+  Geo G = make_geo(c);
+  for (int k = 0; k < ncomp; ++k) {
+    void* fk = (char*)field + (size_t)k * c->vol * smi_elem_size(c);
+    if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, fk, 1));
+    {
+      SmiProfScope prof(c, PROF_ADVECTION, 5.0 * smi_S(c));
+      SMI_DISPATCH(c, {
+        k_advection_flux<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>((T*)flux, (const T*)fk, (const T*)velocity,
+                                                                        (T)(-dt_by_dx), G);
+      });
+      SMI_LAUNCH_CHECK();
+    }
+    SMI_CHECK(smi_elementwise_sum(c, fk, fk, flux, 1));
+  }
+  return 0;
 }

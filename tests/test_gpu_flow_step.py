@@ -95,6 +95,31 @@ def test_navier_stokes_steps(smi, n, flow_type, free_stream, filt, real_t, fused
     assert abs(d_gpu - d_cpu) <= 1e-4 * max(d_cpu, 1e-12)
 
 
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("flow_type", ["passive_scalar", "passive_vector"])
+def test_passive_transport_steps(smi, flow_type, real_t):
+    """flow_simulators_mpi_3d.py:356-380: advect with a prescribed velocity, then diffuse."""
+    rng = np.random.default_rng(5)
+    gpu, cpu = _pair(smi, (16, 16, 32), flow_type, real_t)
+    pshape = cpu.velocity_field.shape[1:]
+    w0 = _blob_vorticity(pshape, cpu.position_field, rng, real_t)
+    field0 = w0[0] if flow_type == "passive_scalar" else w0
+    vel = (rng.random((3,) + pshape) - 0.5).astype(real_t)
+    gpu.velocity_field[...] = vel
+    cpu.velocity_field[...] = vel
+    name = "primary_scalar_field" if flow_type == "passive_scalar" else "primary_vector_field"
+    getattr(gpu, name)[...] = field0
+    getattr(cpu, name)[...] = field0
+    for step in range(3):
+        dt = cpu.compute_stable_timestep(dt_prefac=0.5)
+        assert abs(gpu.compute_stable_timestep(dt_prefac=0.5) - dt) <= 1e-5 * dt
+        gpu.time_step(dt=dt)
+        cpu.time_step(dt=dt)
+        assert_close(getattr(gpu, name).get(), getattr(cpu, name), real_t, factor=2.0 + step,
+                     what=f"{flow_type} step {step}")
+    assert gpu.time == cpu.time
+
+
 def test_simulator_known_answers(smi):
     """The reference's own closed-form checks (tests/test_simulator/test_flow/
     test_flow_simulators_3d.py:333-360, 441-500) run against the GPU simulator."""
