@@ -7,6 +7,7 @@
 // Lagrangian data are float64 and the Eulerian grid is the context's real type, as in
 // the reference (VirtualBoundaryForcingMPI.py:78-81).
 #include "smi_common.h"
+#include "smi_prof.h"
 
 namespace {
 constexpr int kW = 2;          // interp_kernel_width; the reference asserts 2 for both kernels
@@ -329,6 +330,8 @@ extern "C" int smi_ib_forcing_fused(smi_ctx* c, void* lag_forcing, void* lag_vel
   if (m == 0) return 0;
   IbGeo G = make_ibgeo(c, dx, coord_shift, substart_xyz);
   DeltaConst dc = make_delta_const(c, dx);
+  // per node: 64 window cells x 3 components read, 10 doubles of Lagrangian data
+  SmiProfScope prof(c, PROF_IB_FORCING, (double)m * (64.0 * 3 * smi_elem_size(c) + 80.0));
   SMI_DISPATCH(c, {
     k_ib_forcing_fused<T><<<node_blocks(m), 256, 0, c->stream>>>(
         (double*)lag_forcing, (double*)lag_velocity_mismatch, (double*)lag_flow_velocity,
@@ -349,6 +352,8 @@ extern "C" int smi_ib_spread_fused(smi_ctx* c, void* eul_forcing, const void* la
   if (m == 0) return 0;
   IbGeo G = make_ibgeo(c, dx, coord_shift, substart_xyz);
   DeltaConst dc = make_delta_const(c, dx);
+  // per node: 64 window cells x 3 components read-modify-written
+  SmiProfScope prof(c, PROF_IB_SPREAD, (double)m * (64.0 * 3 * 2 * smi_elem_size(c) + 48.0));
   SMI_DISPATCH(c, {
     k_ib_spread_fused<T><<<node_blocks(m), 256, 0, c->stream>>>((T*)eul_forcing, (const double*)lag_forcing,
                                                                (const double*)lag_positions, m, G, kernel_type, dc);

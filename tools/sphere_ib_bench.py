@@ -1,0 +1,82 @@
+"""BASELINE.json configuration 4 (3D 256^3 flow past a rigid sphere with an immersed-boundary
+forcing grid) on one MI355X: navier_stokes_with_forcing, free stream (1, 0, 0), Re = 100,
+sphere D = 0.4 at (0.25, 0.5, 0.5) (examples/3d_examples/FlowPastSphereCase/
+flow_past_sphere_case.py:18-67), Lagrangian nodes = deterministic Fibonacci sphere with
+M = 11 700 points, zero body velocity.  Prints the step time and the per-kernel event timings,
+the interpolation + forcing and the spreading kernels among them.
+
+  python tools/sphere_ib_bench.py [grid] [steps]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sopht-mpi_amd")]
+from sopht_mpi_amd import _lib  # noqa: E402
+from sopht_mpi_amd.simulator import RigidBodyFlowInteractionMPI, UnboundedFlowSimulator3D  # noqa: E402
+from sopht_mpi_amd.simulator.immersed_body import PrescribedForcingGrid  # noqa: E402
+
+
+def fibonacci_sphere(m, radius, centre):
+    k = np.arange(m) + 0.5
+    phi = np.arccos(1 - 2 * k / m)
+    theta = np.pi * (1 + 5**0.5) * k
+    pts = radius * np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)])
+    return pts + np.asarray(centre).reshape(3, 1)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    real_t = np.float32
+    u_inf, diameter, reynolds = 1.0, 0.4, 100.0
+    nu = u_inf * diameter / reynolds
+    sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=nu,
+                                   flow_type="navier_stokes_with_forcing", with_free_stream_flow=True,
+                                   real_t=real_t, ghost_size=2)
+    m = int(round(11700 * (n / 256) ** 2))
+    pos = fibonacci_sphere(m, diameter / 2, (0.25, 0.5, 0.5))
+    spacing = float(np.sqrt(np.pi * diameter**2 / m))
+    interactor = RigidBodyFlowInteractionMPI(
+        mpi_construct=sim.mpi_construct, mpi_ghost_exchange_communicator=sim.mpi_ghost_exchange_communicator,
+        rigid_body=None, eul_grid_forcing_field=sim.eul_grid_forcing_field,
+        eul_grid_velocity_field=sim.velocity_field, virtual_boundary_stiffness_coeff=-6e5 / 4,
+        virtual_boundary_damping_coeff=-3.5e2 / 4, dx=sim.dx, grid_dim=3, forcing_grid_cls=PrescribedForcingGrid,
+        positions=pos, max_spacing=spacing)
+    fs = np.array([u_inf, 0.0, 0.0])
+    sim.compute_flow_velocity(free_stream_velocity=fs)
+
+    def step():
+        dt = sim.compute_stable_timestep(dt_prefac=0.25)
+        interactor()
+        interactor.time_step(dt=dt)
+        sim.time_step(dt=dt, free_stream_velocity=fs)
+
+    for _ in range(5):
+        step()
+    sim.ctx.sync()
+    _lib.call("smi_prof_enable", sim.ctx.handle, 1)
+    _lib.call("smi_prof_reset", sim.ctx.handle)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sim.ctx.sync()
+    el = time.perf_counter() - t0
+    prof = _lib.prof_collect(sim.ctx)
+    interactor.compute_flow_forces_and_torques()
+    out = {"grid": n, "lag_nodes": m, "lag_spacing_over_dx": spacing / float(sim.dx), "steps": steps,
+           "ms_per_step": 1e3 * el / steps, "grid_point_updates_per_s": n**3 * steps / el,
+           "max_vorticity": float(sim.get_max_vorticity()),
+           "grid_deviation_l2": float(interactor.get_grid_deviation_error_l2_norm()),
+           "drag_force_x": float(interactor.body_flow_forces[0, 0]),
+           "kernels": {k: {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"]}
+                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
