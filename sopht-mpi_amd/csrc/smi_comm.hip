@@ -81,9 +81,9 @@ int smi_halo_exchange_impl(smi_ctx* c, void* field, int ncomp) {
 // comes from rank s.  Replaces the Alltoallw transposes inside mpi4py-fft's PFFT
 // (fft_mpi_3d.py:27-48).  One RCCL group of point-to-point pairs: on xGMI every pair has its
 // own link, so all seven peers move at once.
-int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer) {
+int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream) {
   if (c->nranks == 1) {
-    if (send != recv) SMI_CHECK_HIP(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
+    if (send != recv) SMI_CHECK_HIP(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, stream));
     return 0;
   }
   if (c->alltoall_cb) {
@@ -95,13 +95,13 @@ int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per
   // own block: a plain device copy, stream-ordered with the group
   SMI_CHECK_HIP(hipMemcpyAsync((char*)recv + (size_t)c->rank * bytes_per_peer,
                                (const char*)send + (size_t)c->rank * bytes_per_peer, bytes_per_peer,
-                               hipMemcpyDeviceToDevice, c->stream));
+                               hipMemcpyDeviceToDevice, stream));
   SMI_CHECK_NCCL(ncclGroupStart());
   for (int r = 0; r < c->nranks; ++r) {
     if (r == c->rank) continue;
     SMI_CHECK_NCCL(ncclSend((const char*)send + (size_t)r * bytes_per_peer, bytes_per_peer, ncclChar, r, c->comm,
-                            c->stream));
-    SMI_CHECK_NCCL(ncclRecv((char*)recv + (size_t)r * bytes_per_peer, bytes_per_peer, ncclChar, r, c->comm, c->stream));
+                            stream));
+    SMI_CHECK_NCCL(ncclRecv((char*)recv + (size_t)r * bytes_per_peer, bytes_per_peer, ncclChar, r, c->comm, stream));
   }
   SMI_CHECK_NCCL(ncclGroupEnd());
   return 0;

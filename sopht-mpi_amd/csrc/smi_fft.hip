@@ -288,8 +288,10 @@ __device__ __forceinline__ Cx<T> mul_c16(Cx<T> w, int m) {
 constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 
 // Geometry of the spectral buffers.
-//   bufA (exchange layout) : [rank P][comp nc][z nzl][y ny][KXP]      x_fwd out, x_inv in
-//   bufT (after all-to-all): [slab P][comp nc][z nzl][y ny][KXP]      y_fwd in, y_inv out
+//   bufA (exchange layout) : [comp][rank P][z nzl][y ny][KXP]         x_fwd out, x_inv in
+//   bufT (after all-to-all): [comp][slab P][z nzl][y ny][KXP]         y_fwd in, y_inv out
+//                            = [comp][z nz][y ny][KXP]; one component's rank blocks are
+//                            contiguous, so every component is exchanged on its own
 //   bufB                   : [comp nc][z / ZB][ky' 2ny][z % ZB][KXP]   z_conv in place; blocked in z so
 //                            that neither a y tile (all ky' of one z) nor a z tile (all z of one
 //                            ky') strides over more than a few dozen pages
@@ -298,6 +300,7 @@ constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 // KXP = row pitch (KXL rounded up to 16 columns).
 struct PGeo {
   int nz, ny, nx, nzl, P, nc, KXL, KXP, zb_shift;
+  int c0;  // first component of this launch (components c0 .. c0 + nc - 1)
 };
 
 // element offset of bufB row (c, z, ky')
@@ -345,9 +348,9 @@ template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
-  const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
+  const int c = G.c0 + blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
   const bool ok = TS <= 16 || col < G.KXL;
-  const Cx<T>* src = in + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP;
+  const Cx<T>* src = in + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
   Cx<T>* dst = out + rowB(G, c, z, 0);
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
   const unsigned off_in = (unsigned)u * G.KXP + col, off_out = (unsigned)u * kystride + col;
@@ -372,10 +375,10 @@ template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
-  const int c = blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
+  const int c = G.c0 + blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
   const bool ok = TS <= 16 || col < G.KXL;
   const Cx<T>* src = in + rowB(G, c, z, 0);
-  Cx<T>* dst = out + ((((size_t)(z / G.nzl) * G.nc + c) * G.nzl + (z % G.nzl)) * G.ny) * (size_t)G.KXP;
+  Cx<T>* dst = out + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
   const unsigned off_in = (unsigned)u * kystride + col, off_out = (unsigned)u * G.KXP + col;
   Cx<T> v[8], res[8];
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
   const int ntile = nk * G.nc;
   auto tile_base = [&](int it) {
     const int ky = it < G.nc ? kyc : 2 * G.ny - kyc;
-    const int c = it < G.nc ? it : it - G.nc;
+    const int c = G.c0 + (it < G.nc ? it : it - G.nc);
     const int kyp = (ky & 1) * G.ny + (ky >> 1);
     return buf + (size_t)c * cstride + (size_t)kyp * ZB * G.KXP;
   };
@@ -515,11 +518,11 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  const int c = blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
+  const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
   const bool ok = y < G.ny;
   const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
-  const size_t rank_stride = (size_t)G.nc * G.nzl * G.ny * G.KXP;
-  const size_t rowbase = (((size_t)c * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
+  const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXP;
+  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
   const Cx<T> w1 = tw4[1];  // exp(-i pi / 2L)
   Cx<T> v[8], a0[8];
 #pragma unroll
@@ -563,11 +566,11 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  const int c = blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
+  const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
   const bool ok = y < G.ny;
   T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
-  const size_t rank_stride = (size_t)G.nc * G.nzl * G.ny * G.KXP;
-  const size_t rowbase = (((size_t)c * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
+  const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXP;
+  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
   const Cx<T> w1 = tw4[1];
   Cx<T> v[8], res[8];
 #pragma unroll
@@ -632,7 +635,7 @@ int ilog2(int n) {
 
 int smi_greens_spectrum_rocfft(smi_ctx* c, int gnz, int gny, int gnx, double dx, double x_range, void** ghat_out);
 typedef int (*alltoall_fn)(smi_ctx*, const void*, void*, size_t);
-int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer);
+int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream);
 
 struct PrunedState {
   PGeo G;
@@ -643,6 +646,10 @@ struct PrunedState {
   void* bufB = nullptr;
   void* green = nullptr;
   size_t green_bytes = 0;
+  // multi-rank: the transposes run on their own stream, one component at a time, so that they
+  // overlap the transforms of the other components
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev[4][3] = {};
 };
 
 template <typename T>
@@ -662,6 +669,10 @@ int smi_pruned_destroy(smi_poisson* p) {
   PrunedState* s = p->pruned;
   if (!s) return 0;
   for (int i = 0; i < 3; ++i) hipFree(s->tw[i]);
+  for (auto& row : s->ev)
+    for (auto& e : row)
+      if (e) hipEventDestroy(e);
+  if (s->comm_stream) hipStreamDestroy(s->comm_stream);
   if (s->bufT && s->bufT != s->bufA) hipFree(s->bufT);
   hipFree(s->bufA);
   hipFree(s->bufB);
@@ -691,6 +702,7 @@ int smi_pruned_create(smi_poisson* p) {
   G.P = c->nranks;
   G.nzl = c->nz;
   G.nc = 3;
+  G.c0 = 0;
   G.KXL = (G.nx + 1 + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
   // z blocks of at most 16 planes and at most nz / 8 (one work item's elements share z % ZB)
@@ -710,6 +722,9 @@ int smi_pruned_create(smi_poisson* p) {
   if (G.P > 1) {
     SMI_CHECK_HIP(hipMalloc(&s->bufT, nA * cs));
     SMI_CHECK_HIP(hipMemsetAsync(s->bufT, 0, nA * cs, c->stream));
+    SMI_CHECK_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    for (auto& row : s->ev)
+      for (auto& e : row) SMI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   } else {
     s->bufT = s->bufA;
   }
@@ -745,10 +760,11 @@ int smi_pruned_greens_download(smi_poisson* p, void* host) {
 }
 
 template <typename T, int LG>
-static int launch_cols(smi_ctx* c, PrunedState* s, int which, int nc) {
+static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
   // which: 0 = y_fwd, 1 = z_conv, 2 = y_inv
   PGeo G = s->G;
   G.nc = nc;
+  G.c0 = c0;
   using Cfg = TileCfg<T, LG, false>;
   constexpr int TS = Cfg::TS, NT = Cfg::NT;
   const size_t lds_bytes = Cfg::BYTES;
@@ -773,9 +789,10 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int nc) {
 }
 
 template <typename T, int LG>
-static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int nc, void* field) {
+static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, void* field) {
   PGeo G = s->G;
   G.nc = nc;
+  G.c0 = c0;
   using Cfg = TileCfg<T, LG, true>;
   constexpr int TS = Cfg::TS, NT = Cfg::NT;
   const size_t lds_bytes = Cfg::BYTES;
@@ -813,21 +830,54 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
   SMI_REQUIRE(ncomp == 1 || ncomp == 3, "smi_pruned_solve: ncomp must be 1 or 3");
   const PGeo& G = s->G;
   const size_t cs = 2 * smi_elem_size(c);
-  const size_t peer_bytes = (size_t)ncomp * G.nzl * G.ny * G.KXP * cs;
+  if (G.P == 1) {
+    SMI_DISPATCH(c, {
+      LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, true, 0, ncomp, (void*)rhs)));)
+      LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 0, 0, ncomp)));)
+      LG_SWITCH(s->lgz, SMI_CHECK((launch_cols<T, LG>(c, s, 1, 0, ncomp)));)
+      LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 2, 0, ncomp)));)
+      LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, false, 0, ncomp, solution)));)
+    });
+    return 0;
+  }
+  // Slabs.  Per component k:  x_fwd(k) -> transpose(k) -> y_fwd, z_conv, y_inv (k) -> transpose back(k)
+  // -> x_inv(k).  With RCCL the transposes go to the communication stream and events carry the
+  // dependencies, so that a transpose overlaps the transforms of the neighbouring components;
+  // a host-staged transport (callback) is synchronous and everything stays on one stream.
+  const size_t peer_bytes = (size_t)G.nzl * G.ny * G.KXP * cs;   // one component, one peer
+  const size_t comp_bytes = peer_bytes * G.P;
+  const bool overlap = !c->alltoall_cb;
+  hipStream_t cstream = overlap ? s->comm_stream : c->stream;
+  auto transpose = [&](int k, bool back, hipEvent_t ready, hipEvent_t done) -> int {
+    char* a = (char*)s->bufA + (size_t)k * comp_bytes;
+    char* t = (char*)s->bufT + (size_t)k * comp_bytes;
+    if (overlap) {
+      SMI_CHECK_HIP(hipEventRecord(ready, c->stream));
+      SMI_CHECK_HIP(hipStreamWaitEvent(cstream, ready, 0));
+      SMI_CHECK(smi_alltoall_impl(c, back ? t : a, back ? a : t, peer_bytes, cstream));
+      SMI_CHECK_HIP(hipEventRecord(done, cstream));
+    } else {
+      SmiProfScope prof(c, PROF_TRANSPOSE, (double)comp_bytes);
+      SMI_CHECK(smi_alltoall_impl(c, back ? t : a, back ? a : t, peer_bytes, cstream));
+    }
+    return 0;
+  };
   SMI_DISPATCH(c, {
-    LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, true, ncomp, (void*)rhs)));)
-    if (G.P > 1) {
-      SmiProfScope prof(c, PROF_TRANSPOSE, (double)peer_bytes * G.P);
-      SMI_CHECK(smi_alltoall_impl(c, s->bufA, s->bufT, peer_bytes));
+    for (int k = 0; k < ncomp; ++k) {
+      LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, true, k, 1, (void*)rhs)));)
+      SMI_CHECK(transpose(k, false, s->ev[0][k], s->ev[1][k]));
     }
-    LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 0, ncomp)));)
-    LG_SWITCH(s->lgz, SMI_CHECK((launch_cols<T, LG>(c, s, 1, ncomp)));)
-    LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 2, ncomp)));)
-    if (G.P > 1) {
-      SmiProfScope prof(c, PROF_TRANSPOSE, (double)peer_bytes * G.P);
-      SMI_CHECK(smi_alltoall_impl(c, s->bufT, s->bufA, peer_bytes));
+    for (int k = 0; k < ncomp; ++k) {
+      if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[1][k], 0));
+      LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 0, k, 1)));)
+      LG_SWITCH(s->lgz, SMI_CHECK((launch_cols<T, LG>(c, s, 1, k, 1)));)
+      LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 2, k, 1)));)
+      SMI_CHECK(transpose(k, true, s->ev[2][k], s->ev[3][k]));
     }
-    LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, false, ncomp, solution)));)
+    for (int k = 0; k < ncomp; ++k) {
+      if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[3][k], 0));
+      LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, false, k, 1, solution)));)
+    }
   });
   return 0;
 }
