@@ -4,3 +4,10 @@ from .immersed_body_flow_interaction import (  # noqa: F401
     RigidBodyFlowInteractionMPI,
     CosseratRodFlowInteraction,
 )
+from .forcing_grids import (  # noqa: F401,E402
+    CosseratRodElementCentricForcingGrid,
+    CosseratRodSurfaceForcingGrid,
+    RigidSphereBody,
+    SphereForcingGrid,
+    StraightRodBody,
+)

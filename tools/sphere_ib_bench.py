@@ -1,8 +1,8 @@
 """BASELINE.json configuration 4 (3D 256^3 flow past a rigid sphere with an immersed-boundary
 forcing grid) on one MI355X: navier_stokes_with_forcing, free stream (1, 0, 0), Re = 100,
 sphere D = 0.4 at (0.25, 0.5, 0.5) (examples/3d_examples/FlowPastSphereCase/
-flow_past_sphere_case.py:18-67), Lagrangian nodes = deterministic Fibonacci sphere with
-M = 11 700 points, zero body velocity.  Prints the step time and the per-kernel event timings,
+flow_past_sphere_case.py:18-67), SphereForcingGrid with 1.875 D / dx
+points along the equator (11 700 nodes at 256^3), fixed sphere.  Prints the step time and the per-kernel event timings,
 the interpolation + forcing and the spreading kernels among them.
 
   python tools/sphere_ib_bench.py [grid] [steps]
@@ -18,15 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "sopht-mpi_amd")]
 from sopht_mpi_amd import _lib  # noqa: E402
 from sopht_mpi_amd.simulator import RigidBodyFlowInteractionMPI, UnboundedFlowSimulator3D  # noqa: E402
-from sopht_mpi_amd.simulator.immersed_body import PrescribedForcingGrid  # noqa: E402
-
-
-def fibonacci_sphere(m, radius, centre):
-    k = np.arange(m) + 0.5
-    phi = np.arccos(1 - 2 * k / m)
-    theta = np.pi * (1 + 5**0.5) * k
-    pts = radius * np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)])
-    return pts + np.asarray(centre).reshape(3, 1)
+from sopht_mpi_amd.simulator.immersed_body import RigidSphereBody, SphereForcingGrid  # noqa: E402
 
 
 def main():
@@ -38,15 +30,16 @@ def main():
     sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=nu,
                                    flow_type="navier_stokes_with_forcing", with_free_stream_flow=True,
                                    real_t=real_t, ghost_size=2)
-    m = int(round(11700 * (n / 256) ** 2))
-    pos = fibonacci_sphere(m, diameter / 2, (0.25, 0.5, 0.5))
-    spacing = float(np.sqrt(np.pi * diameter**2 / m))
+    sphere = RigidSphereBody(center=(0.25, 0.5, 0.5), base_radius=diameter / 2)
+    num_forcing_points_along_equator = int(1.875 * diameter / 1.0 * n)   # flow_past_sphere_case.py:65-67
     interactor = RigidBodyFlowInteractionMPI(
         mpi_construct=sim.mpi_construct, mpi_ghost_exchange_communicator=sim.mpi_ghost_exchange_communicator,
-        rigid_body=None, eul_grid_forcing_field=sim.eul_grid_forcing_field,
+        rigid_body=sphere, eul_grid_forcing_field=sim.eul_grid_forcing_field,
         eul_grid_velocity_field=sim.velocity_field, virtual_boundary_stiffness_coeff=-6e5 / 4,
-        virtual_boundary_damping_coeff=-3.5e2 / 4, dx=sim.dx, grid_dim=3, forcing_grid_cls=PrescribedForcingGrid,
-        positions=pos, max_spacing=spacing)
+        virtual_boundary_damping_coeff=-3.5e2 / 4, dx=sim.dx, grid_dim=3, forcing_grid_cls=SphereForcingGrid,
+        num_forcing_points_along_equator=num_forcing_points_along_equator)
+    m = interactor.forcing_grid.num_lag_nodes
+    spacing = interactor.forcing_grid.get_maximum_lagrangian_grid_spacing()
     fs = np.array([u_inf, 0.0, 0.0])
     sim.compute_flow_velocity(free_stream_velocity=fs)
 
