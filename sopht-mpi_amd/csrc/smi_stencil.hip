@@ -435,6 +435,199 @@ __global__ void __launch_bounds__(kAdvectBlock) k_advect(T* __restrict__ out, co
   for (int z = ze + 1; z < z1; ++z) copy_plane(z);
 }
 
+// ---------------------------------------------------------------- fused advection, LDS tiled
+// Same operator as k_advect on the 16-byte path, organised so that HBM sees every input cell
+// once: a workgroup owns a tile of TY rows x 4 TXL columns and marches along z.  b = u x w of
+// the plane ahead is formed by the lane that owns the cell (and by a few lanes for the ring of
+// halo cells around the tile) and parked in one of two LDS tiles; a step later the curl stencil
+// reads its y+-1 / x+-1 neighbours from there.  One barrier per plane: a lane writes plane z+1
+// into the other tile only after the barrier of step z, which every lane reaches after its
+// reads of step z-1.
+struct TileShape {
+  int txl, ty, ntx, nty;  // lanes (of 4 cells) per tile row, rows per tile, tiles per plane
+  int pitch, rows;        // LDS row pitch in elements (own cells start at column 4), ty + 2
+};
+
+template <typename T>
+__device__ __forceinline__ void cross3(const Pack<T, 4>& ux, const Pack<T, 4>& uy, const Pack<T, 4>& uz,
+                                       const Pack<T, 4>& wx, const Pack<T, 4>& wy, const Pack<T, 4>& wz,
+                                       Pack<T, 4>& bx, Pack<T, 4>& by, Pack<T, 4>& bz) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bx.v[e] = uy.v[e] * wz.v[e] - uz.v[e] * wy.v[e];
+    by.v[e] = uz.v[e] * wx.v[e] - ux.v[e] * wz.v[e];
+    bz.v[e] = ux.v[e] * wy.v[e] - uy.v[e] * wx.v[e];
+  }
+}
+
+constexpr int kTileThreads = 512;
+
+template <typename T>
+__global__ void __launch_bounds__(kTileThreads) k_advect_tiled(T* __restrict__ out, const T* __restrict__ vel,
+                                                              const T* __restrict__ vort, T pref, Geo G,
+                                                              int zchunk, TileShape S) {
+  extern __shared__ char smi_tile_smem[];
+  T* lds = reinterpret_cast<T*>(smi_tile_smem);
+  const Blk B = xcd_block<true>();
+  const int tyi = B.x / S.ntx, txi = B.x - tyi * S.ntx;
+  const int tid = threadIdx.x;
+  const int ly = tid / S.txl, lx = tid - ly * S.txl;
+  const int ty0 = tyi * S.ty, tx0 = txi * S.txl * 4;
+  const int y = ty0 + ly, x0 = tx0 + 4 * lx;
+  const bool own = ly < S.ty && y < G.py && x0 < G.px;
+  const long long q = (long long)y * G.px + x0;
+  const size_t comp = (size_t)S.rows * S.pitch;  // LDS elements per component tile
+  auto tile = [&](int buf, int c) { return lds + ((size_t)buf * 3 + c) * comp; };
+  const int own_off = (ly + 1) * S.pitch + 4 + 4 * lx;
+  // halo ring duty of this lane (lanes 0 .. 2 txl + 2 ty - 1)
+  const int nrow = 2 * S.txl, ntask = nrow + 2 * S.ty;
+  bool h_on = tid < ntask, h_vec = tid < nrow;
+  int hy, hx, h_off;
+  if (h_vec) {
+    const int top = tid >= S.txl, hl = tid - top * S.txl;
+    hy = top ? ty0 + S.ty : ty0 - 1;
+    hx = tx0 + 4 * hl;
+    h_off = (top ? S.ty + 1 : 0) * S.pitch + 4 + 4 * hl;
+    h_on = h_on && hy >= 0 && hy < G.py && hx < G.px;
+  } else {
+    const int k = tid - nrow, right = k >= S.ty, r = k - right * S.ty;
+    hy = ty0 + r;
+    hx = right ? tx0 + 4 * S.txl : tx0 - 1;
+    h_off = (r + 1) * S.pitch + (right ? 4 + 4 * S.txl : 3);
+    h_on = h_on && hy < G.py && hx >= 0 && hx < G.px;
+  }
+  const long long hq = (long long)hy * G.px + hx;
+
+  bool mA[4], mB[4];
+  {
+    const bool yc = in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
+      mA[e] = own && yc && xc;
+      mB[e] = own && ((yf && xc) || (ye && xf));
+    }
+  }
+  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  const int zs = max(z0, 1), ze = min(z1 - 1, G.pz - 2);
+  auto copy_plane = [&](int z) {
+    if (!own) return;
+    const long long zo = z * G.plane + q;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st<T, 4>(out + c * G.vol + zo, ld<T, 4>(vort + c * G.vol + zo));
+  };
+  if (zs > ze) {  // uniform over the workgroup
+    for (int z = z0; z < z1; ++z) copy_plane(z);
+    return;
+  }
+  for (int z = z0; z < zs; ++z) copy_plane(z);
+
+  // b of one plane into a tile: the lane's own four cells and its halo duty
+  auto load_own = [&](int z, Vec3<T, 4>& u, Vec3<T, 4>& w) {
+    if (own) {
+      u = ld3<T, 4>(vel + z * G.plane + q, G.vol);
+      w = ld3<T, 4>(vort + z * G.plane + q, G.vol);
+    } else {
+      u = w = Vec3<T, 4>{zero_pack<T, 4>(), zero_pack<T, 4>(), zero_pack<T, 4>()};
+    }
+  };
+  auto park = [&](int buf, const Pack<T, 4>& bx, const Pack<T, 4>& by, const Pack<T, 4>& bz) {
+    if (!own) return;
+    st<T, 4>(tile(buf, 0) + own_off, bx);
+    st<T, 4>(tile(buf, 1) + own_off, by);
+    st<T, 4>(tile(buf, 2) + own_off, bz);
+  };
+  auto halo = [&](int z, int buf) {
+    if (!h_on) return;
+    const T* u = vel + z * G.plane + hq;
+    const T* w = vort + z * G.plane + hq;
+    if (h_vec) {
+      Vec3<T, 4> a = ld3<T, 4>(u, G.vol), b = ld3<T, 4>(w, G.vol);
+      Pack<T, 4> bx, by, bz;
+      cross3(a.x, a.y, a.z, b.x, b.y, b.z, bx, by, bz);
+      st<T, 4>(tile(buf, 0) + h_off, bx);
+      st<T, 4>(tile(buf, 1) + h_off, by);
+      st<T, 4>(tile(buf, 2) + h_off, bz);
+    } else {
+      const T ax = u[0], ay = u[G.vol], az = u[2 * G.vol], cx = w[0], cy = w[G.vol], cz = w[2 * G.vol];
+      tile(buf, 0)[h_off] = ay * cz - az * cy;
+      tile(buf, 1)[h_off] = az * cx - ax * cz;
+      tile(buf, 2)[h_off] = ax * cy - ay * cx;
+    }
+  };
+
+  Pack<T, 4> bx_p, by_p, bx_c, by_c, bz_c;
+  Vec3<T, 4> w_c;
+  {
+    Vec3<T, 4> u, w;
+    load_own(zs - 1, u, w);
+    Pack<T, 4> bz_unused;
+    cross3(u.x, u.y, u.z, w.x, w.y, w.z, bx_p, by_p, bz_unused);
+    load_own(zs, u, w_c);
+    cross3(u.x, u.y, u.z, w_c.x, w_c.y, w_c.z, bx_c, by_c, bz_c);
+    park(zs & 1, bx_c, by_c, bz_c);
+    halo(zs, zs & 1);
+  }
+  for (int z = zs; z <= ze; ++z) {
+    Vec3<T, 4> u_n, w_n;
+    load_own(z + 1, u_n, w_n);  // in flight across the barrier
+    __syncthreads();
+    const int buf = z & 1;
+    if (own) {
+      const T* tx = tile(buf, 0) + own_off;
+      const T* ty = tile(buf, 1) + own_off;
+      const T* tz = tile(buf, 2) + own_off;
+      const Pack<T, 4> bx_ym = ld<T, 4>(tx - S.pitch), bx_yp = ld<T, 4>(tx + S.pitch);
+      const Pack<T, 4> bz_ym = ld<T, 4>(tz - S.pitch), bz_yp = ld<T, 4>(tz + S.pitch);
+      const T by_xm = ty[-1], by_xp = ty[4], bz_xm = tz[-1], bz_xp = tz[4];
+      const bool zA = z >= G.g && z <= G.pz - G.g - 1;
+      Pack<T, 4> rx, ry, rz;
+      // needs b_x, b_y of the plane ahead: computed below from u_n, w_n, so form it first
+      Pack<T, 4> bx_n, by_n, bz_n;
+      cross3(u_n.x, u_n.y, u_n.z, w_n.x, w_n.y, w_n.z, bx_n, by_n, bz_n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const T byL = e == 0 ? by_xm : by_c.v[e - 1], byR = e == 3 ? by_xp : by_c.v[e + 1];
+        const T bzL = e == 0 ? bz_xm : bz_c.v[e - 1], bzR = e == 3 ? bz_xp : bz_c.v[e + 1];
+        const bool m = mB[e] || (mA[e] && zA);
+        const T cx = pref * (bz_yp.v[e] - bz_ym.v[e] - by_n.v[e] + by_p.v[e]);
+        const T cy = pref * (bx_n.v[e] - bx_p.v[e] - bzR + bzL);
+        const T cz = pref * (byR - byL - bx_yp.v[e] + bx_ym.v[e]);
+        rx.v[e] = m ? w_c.x.v[e] + cx : w_c.x.v[e];
+        ry.v[e] = m ? w_c.y.v[e] + cy : w_c.y.v[e];
+        rz.v[e] = m ? w_c.z.v[e] + cz : w_c.z.v[e];
+      }
+      const long long zo = z * G.plane + q;
+      st<T, 4>(out + zo, rx);
+      st<T, 4>(out + G.vol + zo, ry);
+      st<T, 4>(out + 2 * G.vol + zo, rz);
+      bx_p = bx_c;
+      by_p = by_c;
+      bx_c = bx_n;
+      by_c = by_n;
+      bz_c = bz_n;
+      w_c = w_n;
+      park(buf ^ 1, bx_c, by_c, bz_c);
+    }
+    if (z < ze) halo(z + 1, buf ^ 1);
+  }
+  for (int z = ze + 1; z < z1; ++z) copy_plane(z);
+}
+
+template <typename T>
+static TileShape tile_shape(const smi_ctx* c) {
+  TileShape S;
+  const int lanes = c->px / 4;
+  S.ntx = (lanes + 31) / 32;
+  S.txl = (lanes + S.ntx - 1) / S.ntx;
+  S.ty = kTileThreads / S.txl;
+  if (S.ty > 8) S.ty = 8;  // four-wave workgroups: several fit on a CU and hide each other's barriers
+  S.nty = (c->py + S.ty - 1) / S.ty;
+  S.pitch = 4 * S.txl + 8;
+  S.rows = S.ty + 2;
+  return S;
+}
+
 // ---------------------------------------------------------------- conservative advection flux
 // flux = c * sum over axes of (F(i+1/2) - F(i-1/2)) on W, 0 elsewhere, with the face flux
 //   F(i+1/2) = v_f * (v_f > 0 ? (-f[i-1] + 5 f[i] + 2 f[i+1]) / 6 : (2 f[i] + 5 f[i+1] - f[i+2]) / 6),
@@ -681,9 +874,20 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
   SmiProfScope prof(c, PROF_FUSED_ADVECT, 9.0 * smi_S(c));
   SMI_DISPATCH(c, {
     if (vec_ok<T>(c, out, velocity) && vec_ok<T>(c, out, vorticity)) {
-      LaunchShape s = plan<4, kAdvectBlock>(c, 1);
-      k_advect<T, 4><<<s.grid, kAdvectBlock, 0, c->stream>>>((T*)out, (const T*)velocity, (const T*)vorticity,
-                                                       (T)prefactor, G, s.zchunk);
+      const TileShape S = tile_shape<T>(c);
+      const size_t lds_bytes = (size_t)2 * 3 * S.rows * S.pitch * sizeof(T);
+      static bool attr_set = false;
+      if (!attr_set) {
+        SMI_CHECK_HIP(hipFuncSetAttribute((const void*)k_advect_tiled<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          128 * 1024));
+        attr_set = true;
+      }
+      // short z chunks (two halo planes per 16) measured faster than long ones: more, shorter workgroups
+      int zchunk = c->pz < 16 ? c->pz : 16;
+      dim3 grid(S.ntx * S.nty, (c->pz + zchunk - 1) / zchunk, 1);
+      const int threads = (S.txl * S.ty + 63) / 64 * 64;  // whole waves covering the tile and its halo duty
+      k_advect_tiled<T><<<grid, threads, lds_bytes, c->stream>>>((T*)out, (const T*)velocity,
+                                                                      (const T*)vorticity, (T)prefactor, G, zchunk, S);
     } else {
       LaunchShape s = plan<1, kAdvectBlock>(c, 1);
       k_advect<T, 1><<<s.grid, kAdvectBlock, 0, c->stream>>>((T*)out, (const T*)velocity, (const T*)vorticity,
