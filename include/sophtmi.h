@@ -213,6 +213,40 @@ int smi_flow_step_ns3d(smi_ctx* ctx, smi_poisson* p, void* vorticity, void* velo
                        const double* fac_hi, const double* free_stream, int filter_order,
                        int filter_type);
 
+/* ---- 2D flow path --------------------------------------------------------------------
+ * Operators of UnboundedFlowSimulator2D (simulator/flow/flow_simulators_mpi_2d.py:166-298) on
+ * ghosted [y][x] arrays of (ny + 2g) * (nx + 2g) reals; vectors are (2, y, x) with component
+ * 0 = x.  Single rank: ctx must have been created with nz = 1 and nranks = 1 (its ny, nx and
+ * ghost describe the plane). */
+typedef struct smi_poisson2d smi_poisson2d;
+/* stencil_ops_2d/diffusion_flux_mpi_2d.py:30-136 */
+int smi2d_diffusion_flux(smi_ctx* ctx, void* flux, const void* field, double prefactor);
+/* stencil_ops_2d/diffusion_timestep_mpi_2d.py */
+int smi2d_diffusion_timestep(smi_ctx* ctx, void* field, void* flux, double nu_dt_by_dx2);
+/* stencil_ops_2d/advection_timestep_mpi_2d.py, advection_flux_mpi_2d.py (kernel support 2) */
+int smi2d_advection_timestep_eno3(smi_ctx* ctx, void* field, void* flux, const void* velocity,
+                                  double dt_by_dx);
+/* stencil_ops_2d/outplane_field_curl_mpi_2d.py:30-139 (stream function -> velocity) */
+int smi2d_outplane_field_curl(smi_ctx* ctx, void* curl, const void* field, double prefactor);
+/* stencil_ops_2d/update_vorticity_from_velocity_forcing_mpi_2d.py */
+int smi2d_update_vorticity_from_velocity_forcing(smi_ctx* ctx, void* vorticity,
+                                                 const void* forcing, double prefactor);
+/* stencil_ops_2d/penalise_field_boundary_mpi_2d.py:9-172; factor tables [x band | y band] */
+int smi2d_penalise_boundary(smi_ctx* ctx, void* field, int width, const double* fac_lo,
+                            const double* fac_hi);
+/* sopht set_fixed_val / add_fixed_val as used by flow_simulators_mpi_2d.py:217-233 */
+int smi2d_set_fixed_val(smi_ctx* ctx, void* field, int ncomp, const double* vals);
+int smi2d_add_fixed_val(smi_ctx* ctx, void* sum_field, const void* field, int ncomp,
+                        const double* vals);
+/* interior max of |u| + |v| and of a scalar (flow_simulators_mpi_2d.py:300-328) */
+int smi2d_reduce_max_abs_sum(smi_ctx* ctx, const void* vector_field, double* out);
+int smi2d_reduce_max(smi_ctx* ctx, const void* field, double* out);
+/* poisson_solver_2d/UnboundedPoissonSolverMPI2D.py:20-153.  greens_host: the (2ny, 2nx)
+ * Green's function field of :61-107 in the context's real type, built by the caller. */
+int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* ctx, const void* greens_host, double dx);
+int smi2d_poisson_destroy(smi_poisson2d* p);
+int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void* rhs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,412 @@
+// 2D flow path of libsophtmi (gfx950): the operators of UnboundedFlowSimulator2D
+// (sopht_mpi/simulator/flow/flow_simulators_mpi_2d.py:166-298) on ghosted [y][x] arrays.
+//
+// 2D grids are tiny next to the 3D ones (256^2 in the reference's own case), so these
+// kernels are plain one-lane-per-cell kernels: coalesced along x, neighbours through L1/L2.
+// Single rank only.  The context must have been created with nz = 1; its ny, nx and ghost
+// width describe the plane, arrays are (ny + 2g) * (nx + 2g) reals owned by the caller.
+//
+// Which cells an operator writes follows the five overlapping boxes of the reference
+// wrappers (diffusion_flux_mpi_2d.py:47-113) and their band zeroing (:116-136), exactly as in
+// 3D: with core_s(a) = a in [g+s, p-g-s-1], face_s(a) = a in [g, g+s-1] or [p-g-s, p-g-1],
+// ext_s(a) = a in [s, p-s-1]:
+//   D   = { core_1(y), core_1(x) }                                             flux, curl
+//   U_s = { y in [g, p-g-1], core_s(x) } + { ext_s(y), face_s(x) }             forcing update (s = 1),
+//                                                                              advection (s = 2)
+#include <hipfft/hipfft.h>
+
+#include "smi_common.h"
+
+#define SMI_CHECK_FFT2(expr)                                                              \
+  do {                                                                                    \
+    hipfftResult _e = (expr);                                                             \
+    if (_e != HIPFFT_SUCCESS) {                                                           \
+      smi_set_error("%s:%d: %s -> hipfft error %d", __FILE__, __LINE__, #expr, (int)_e);  \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+struct smi_poisson2d {
+  smi_ctx* ctx;
+  int ny, nx;
+  hipfftHandle fwd, inv;
+  void* real_buf;   // (2ny, 2nx) reals
+  void* cplx_buf;   // (2ny, nx + 1) complex
+  void* ghat;       // (2ny, nx + 1) complex, times dx^2 / (4 ny nx)
+};
+
+namespace {
+
+constexpr int kB = 256;
+
+struct G2 {
+  int py, px, g;
+  long long n;  // py * px
+};
+
+G2 geo2(const smi_ctx* c) { return G2{c->py, c->px, c->g, (long long)c->py * c->px}; }
+int nblocks(long long n) { return (int)((n + kB - 1) / kB); }
+
+__device__ __forceinline__ bool core_s(int a, int p, int g, int s) { return a >= g + s && a <= p - g - s - 1; }
+__device__ __forceinline__ bool face_s(int a, int p, int g, int s) {
+  return (a >= g && a <= g + s - 1) || (a >= p - g - s && a <= p - g - 1);
+}
+__device__ __forceinline__ bool ext_s(int a, int p, int s) { return a >= s && a <= p - s - 1; }
+__device__ __forceinline__ bool in_update_set(int y, int x, const G2& G, int s) {
+  return (y >= G.g && y <= G.py - G.g - 1 && core_s(x, G.px, G.g, s)) ||
+         (ext_s(y, G.py, s) && face_s(x, G.px, G.g, s));
+}
+
+// flux = c (f(x+1) + f(x-1) + f(y+1) + f(y-1) - 4 f) on D, 0 elsewhere; ADD: out = f + flux
+template <typename T, bool ADD>
+__global__ void __launch_bounds__(kB) k2_diffusion(T* __restrict__ out, const T* __restrict__ f, T c, G2 G) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.n) return;
+  const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
+  T v = T(0);
+  if (core_s(y, G.py, G.g, 1) && core_s(x, G.px, G.g, 1))
+    v = c * (f[i + 1] + f[i - 1] + f[i + G.px] + f[i - G.px] - T(4) * f[i]);
+  out[i] = ADD ? f[i] + v : v;
+}
+
+template <typename T>
+__device__ __forceinline__ T upwind3_face2(const T* f, const T* v, long long stride) {
+  const T vf = T(0.5) * (v[0] + v[stride]);
+  const T left = T(-1.0 / 6) * f[-stride] + T(5.0 / 6) * f[0] + T(1.0 / 3) * f[stride];
+  const T right = T(1.0 / 3) * f[0] + T(5.0 / 6) * f[stride] + T(-1.0 / 6) * f[2 * stride];
+  return vf * (vf > T(0) ? left : right);
+}
+
+// flux = c * (dF_x/dx + dF_y/dy) with the third-order upwind face flux, on U_2, 0 elsewhere
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_advection_flux(T* __restrict__ flux, const T* __restrict__ f,
+                                                       const T* __restrict__ vel, T c, G2 G) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.n) return;
+  const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
+  T val = T(0);
+  if (in_update_set(y, x, G, 2)) {
+    const T* fc = f + i;
+    const T* vx = vel + i;
+    const T* vy = vel + G.n + i;
+    const T dx = upwind3_face2(fc, vx, 1) - upwind3_face2(fc - 1, vx - 1, 1);
+    const T dy = upwind3_face2(fc, vy, (long long)G.px) - upwind3_face2(fc - G.px, vy - G.px, (long long)G.px);
+    val = c * (dx + dy);
+  }
+  flux[i] = val;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_sum(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                            long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+
+// u = p d(psi)/dy, v = -p d(psi)/dx on D, 0 elsewhere (outplane_field_curl_mpi_2d.py)
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_outplane_curl(T* __restrict__ curl, const T* __restrict__ f, T p, G2 G) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.n) return;
+  const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
+  T u = T(0), v = T(0);
+  if (core_s(y, G.py, G.g, 1) && core_s(x, G.px, G.g, 1)) {
+    u = p * (f[i + G.px] - f[i - G.px]);
+    v = -p * (f[i + 1] - f[i - 1]);
+  }
+  curl[i] = u;
+  curl[G.n + i] = v;
+}
+
+// w += p (d f_y / dx - d f_x / dy) on U_1 (update_vorticity_from_velocity_forcing_mpi_2d.py)
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_update_vorticity(T* __restrict__ w, const T* __restrict__ f, T p, G2 G) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.n) return;
+  const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
+  if (!in_update_set(y, x, G, 1)) return;
+  const T* fx = f + i;
+  const T* fy = f + G.n + i;
+  w[i] += p * ((fy[1] - fy[-1]) - (fx[G.px] - fx[-G.px]));
+}
+
+struct PenFac2 {
+  double lo[2][16], hi[2][16];  // [axis x, y][band index]
+};
+
+// AXIS 0: one lane per row, AXIS 1: one lane per column (penalise_field_boundary_mpi_2d.py:139-170)
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(kB) k2_penalise(T* __restrict__ f, G2 G, int w, PenFac2 fac) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lines = AXIS == 0 ? G.py : G.px;
+  if (l >= lines) return;
+  T* base = AXIS == 0 ? f + (long long)l * G.px : f + l;
+  const long long stride = AXIS == 0 ? 1 : G.px;
+  const int p = AXIS == 0 ? G.px : G.py;
+  const T lo_src = base[(w - 1) * stride];
+  for (int k = 0; k < w; ++k) base[k * stride] = lo_src * (T)fac.lo[AXIS][k];
+  const T hi_src = base[(p - w) * stride];
+  for (int k = 0; k < w; ++k) base[(p - w + k) * stride] = hi_src * (T)fac.hi[AXIS][k];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_set_add(T* __restrict__ out, const T* __restrict__ in, T val, long long n,
+                                                int add) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = add ? in[i] + val : val;
+}
+
+// One-block reductions over the interior.  MODE 0: max of |u| + |v|; MODE 1: max of f.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(1024) k2_reduce_max(const T* __restrict__ f, G2 G, double* __restrict__ out) {
+  __shared__ double part[1024];
+  const int ny = G.py - 2 * G.g, nx = G.px - 2 * G.g;
+  double m = -1.0e300;
+  for (long long k = threadIdx.x; k < (long long)ny * nx; k += blockDim.x) {
+    const int y = (int)(k / nx) + G.g, x = (int)(k % nx) + G.g;
+    const long long i = (long long)y * G.px + x;
+    const T v = MODE == 0 ? (T)(fabs(f[i]) + fabs(f[G.n + i])) : f[i];
+    m = fmax(m, (double)v);
+  }
+  part[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) part[threadIdx.x] = fmax(part[threadIdx.x], part[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = part[0];
+}
+
+// ---- Poisson helpers
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_pad_load(T* __restrict__ dbl, const T* __restrict__ rhs, int ny, int nx,
+                                                 int g, int px) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = 4LL * ny * nx;
+  if (i >= n) return;
+  const int y = (int)(i / (2 * nx)), x = (int)(i - (long long)y * 2 * nx);
+  dbl[i] = (y < ny && x < nx) ? rhs[(long long)(y + g) * px + x + g] : T(0);
+}
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_cmul(T* __restrict__ a, const T* __restrict__ b, long long ncplx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncplx) return;
+  const T ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+  a[2 * i] = ar * br - ai * bi;
+  a[2 * i + 1] = ar * bi + ai * br;
+}
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_scale(T* __restrict__ a, T s, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= s;
+}
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_extract(T* __restrict__ sol, const T* __restrict__ dbl, int ny, int nx,
+                                                int g, int px) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)ny * nx) return;
+  const int y = (int)(i / nx), x = (int)(i - (long long)y * nx);
+  sol[(long long)(y + g) * px + x + g] = dbl[(long long)y * 2 * nx + x];
+}
+
+int require_2d(const smi_ctx* c, const char* who) {
+  SMI_REQUIRE(c, "%s: null context", who);
+  SMI_REQUIRE(c->nz == 1 && c->nranks == 1, "%s: the 2D operators need a single-rank context created with nz = 1", who);
+  return 0;
+}
+
+template <typename T>
+int fft_forward(smi_poisson2d* p, void* real_in, void* cplx_out) {
+  if (sizeof(T) == 4)
+    SMI_CHECK_FFT2(hipfftExecR2C(p->fwd, (hipfftReal*)real_in, (hipfftComplex*)cplx_out));
+  else
+    SMI_CHECK_FFT2(hipfftExecD2Z(p->fwd, (hipfftDoubleReal*)real_in, (hipfftDoubleComplex*)cplx_out));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int smi2d_diffusion_flux(smi_ctx* c, void* flux, const void* field, double prefactor) {
+  SMI_CHECK(require_2d(c, "smi2d_diffusion_flux"));
+  SMI_REQUIRE(flux && field && flux != field, "smi2d_diffusion_flux: bad argument");
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, { k2_diffusion<T, false><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (T)prefactor, G); });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_diffusion_timestep(smi_ctx* c, void* field, void* flux, double nu_dt_by_dx2) {
+  SMI_CHECK(smi2d_diffusion_flux(c, flux, field, nu_dt_by_dx2));
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, { k2_sum<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)field, (const T*)field, (const T*)flux, G.n); });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_advection_timestep_eno3(smi_ctx* c, void* field, void* flux, const void* velocity,
+                                             double dt_by_dx) {
+  SMI_CHECK(require_2d(c, "smi2d_advection_timestep_eno3"));
+  SMI_REQUIRE(field && flux && velocity && flux != field, "smi2d_advection_timestep_eno3: bad argument");
+  SMI_REQUIRE(c->g >= 2, "smi2d_advection_timestep_eno3: kernel support 2 needs ghost_size >= 2 (got %d)", c->g);
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, {
+    k2_advection_flux<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (const T*)velocity,
+                                                            (T)(-dt_by_dx), G);
+    k2_sum<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)field, (const T*)field, (const T*)flux, G.n);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_outplane_field_curl(smi_ctx* c, void* curl, const void* field, double prefactor) {
+  SMI_CHECK(require_2d(c, "smi2d_outplane_field_curl"));
+  SMI_REQUIRE(curl && field && curl != field, "smi2d_outplane_field_curl: bad argument");
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, { k2_outplane_curl<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)curl, (const T*)field, (T)prefactor, G); });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vorticity, const void* forcing,
+                                                            double prefactor) {
+  SMI_CHECK(require_2d(c, "smi2d_update_vorticity_from_velocity_forcing"));
+  SMI_REQUIRE(vorticity && forcing && vorticity != forcing, "smi2d_update_vorticity_from_velocity_forcing: bad argument");
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, {
+    k2_update_vorticity<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)vorticity, (const T*)forcing, (T)prefactor, G);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_penalise_boundary(smi_ctx* c, void* field, int width, const double* fac_lo, const double* fac_hi) {
+  SMI_CHECK(require_2d(c, "smi2d_penalise_boundary"));
+  SMI_REQUIRE(field, "smi2d_penalise_boundary: bad argument");
+  SMI_REQUIRE(width >= 0, "invalid zone width");
+  if (width == 0) return 0;
+  const int w = c->g + width;
+  SMI_REQUIRE(w <= 16, "smi2d_penalise_boundary: ghost + width = %d exceeds 16", w);
+  SMI_REQUIRE(fac_lo && fac_hi, "smi2d_penalise_boundary: null factor tables");
+  SMI_REQUIRE(2 * w <= c->px && 2 * w <= c->py, "smi2d_penalise_boundary: penalty bands overlap on this grid");
+  PenFac2 fac;
+  for (int a = 0; a < 2; ++a)
+    for (int k = 0; k < w; ++k) {
+      fac.lo[a][k] = fac_lo[a * w + k];
+      fac.hi[a][k] = fac_hi[a * w + k];
+    }
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, {
+    k2_penalise<T, 0><<<nblocks(G.py), kB, 0, c->stream>>>((T*)field, G, w, fac);
+    k2_penalise<T, 1><<<nblocks(G.px), kB, 0, c->stream>>>((T*)field, G, w, fac);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+static int set_add2(smi_ctx* c, void* out, const void* in, int ncomp, const double* vals, int add) {
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, {
+    for (int k = 0; k < ncomp; ++k)
+      k2_set_add<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)out + k * G.n, (const T*)in + k * G.n, (T)vals[k], G.n, add);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_set_fixed_val(smi_ctx* c, void* field, int ncomp, const double* vals) {
+  SMI_CHECK(require_2d(c, "smi2d_set_fixed_val"));
+  SMI_REQUIRE(field && vals && ncomp >= 1, "smi2d_set_fixed_val: bad argument");
+  return set_add2(c, field, field, ncomp, vals, 0);
+}
+
+extern "C" int smi2d_add_fixed_val(smi_ctx* c, void* sum_field, const void* field, int ncomp, const double* vals) {
+  SMI_CHECK(require_2d(c, "smi2d_add_fixed_val"));
+  SMI_REQUIRE(sum_field && field && vals && ncomp >= 1, "smi2d_add_fixed_val: bad argument");
+  return set_add2(c, sum_field, field, ncomp, vals, 1);
+}
+
+template <int MODE>
+static int reduce2(smi_ctx* c, const void* f, double* out) {
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, { k2_reduce_max<T, MODE><<<1, 1024, 0, c->stream>>>((const T*)f, G, (double*)c->red_partials); });
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK_HIP(hipMemcpyAsync(c->red_host, c->red_partials, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  *out = c->red_host[0];
+  return 0;
+}
+
+extern "C" int smi2d_reduce_max_abs_sum(smi_ctx* c, const void* vector_field, double* out) {
+  SMI_CHECK(require_2d(c, "smi2d_reduce_max_abs_sum"));
+  SMI_REQUIRE(vector_field && out, "smi2d_reduce_max_abs_sum: bad argument");
+  return reduce2<0>(c, vector_field, out);
+}
+
+extern "C" int smi2d_reduce_max(smi_ctx* c, const void* field, double* out) {
+  SMI_CHECK(require_2d(c, "smi2d_reduce_max"));
+  SMI_REQUIRE(field && out, "smi2d_reduce_max: bad argument");
+  return reduce2<1>(c, field, out);
+}
+
+// ---- unbounded Poisson solve in 2D (UnboundedPoissonSolverMPI2D.py:61-153): pad to (2ny, 2nx),
+// real-to-complex FFT, multiply by the transformed Green's function times dx^2, inverse, crop.
+extern "C" int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* c, const void* greens_host, double dx) {
+  SMI_CHECK(require_2d(c, "smi2d_poisson_create"));
+  SMI_REQUIRE(out && greens_host, "smi2d_poisson_create: bad argument");
+  smi_poisson2d* p = new smi_poisson2d();
+  p->ctx = c;
+  p->ny = c->ny;
+  p->nx = c->nx;
+  const size_t es = smi_elem_size(c);
+  const size_t nreal = 4 * (size_t)p->ny * p->nx, ncplx = 2 * (size_t)p->ny * (p->nx + 1);
+  const bool f32 = c->dtype == SMI_F32;
+  SMI_CHECK_HIP(hipSetDevice(c->device));
+  SMI_CHECK_HIP(hipMalloc(&p->real_buf, nreal * es));
+  SMI_CHECK_HIP(hipMalloc(&p->cplx_buf, ncplx * 2 * es));
+  SMI_CHECK_HIP(hipMalloc(&p->ghat, ncplx * 2 * es));
+  SMI_CHECK_FFT2(hipfftPlan2d(&p->fwd, 2 * p->ny, 2 * p->nx, f32 ? HIPFFT_R2C : HIPFFT_D2Z));
+  SMI_CHECK_FFT2(hipfftPlan2d(&p->inv, 2 * p->ny, 2 * p->nx, f32 ? HIPFFT_C2R : HIPFFT_Z2D));
+  SMI_CHECK_FFT2(hipfftSetStream(p->fwd, c->stream));
+  SMI_CHECK_FFT2(hipfftSetStream(p->inv, c->stream));
+  SMI_CHECK_HIP(hipMemcpyAsync(p->real_buf, greens_host, nreal * es, hipMemcpyHostToDevice, c->stream));
+  // dx^2 of the reference and the 1 / (2ny 2nx) of its normalised backward transform, folded in
+  const double scale = dx * dx / (4.0 * (double)p->ny * (double)p->nx);
+  SMI_DISPATCH(c, {
+    SMI_CHECK((fft_forward<T>(p, p->real_buf, p->ghat)));
+    k2_scale<T><<<nblocks(2 * (long long)ncplx), kB, 0, c->stream>>>((T*)p->ghat, (T)scale, 2 * (long long)ncplx);
+  });
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  *out = p;
+  return 0;
+}
+
+extern "C" int smi2d_poisson_destroy(smi_poisson2d* p) {
+  if (!p) return 0;
+  if (p->fwd) hipfftDestroy(p->fwd);
+  if (p->inv) hipfftDestroy(p->inv);
+  hipFree(p->real_buf);
+  hipFree(p->cplx_buf);
+  hipFree(p->ghat);
+  delete p;
+  return 0;
+}
+
+extern "C" int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void* rhs) {
+  SMI_REQUIRE(p && solution && rhs, "smi2d_poisson_solve: bad argument");
+  smi_ctx* c = p->ctx;
+  const long long nreal = 4LL * p->ny * p->nx, ncplx = 2LL * p->ny * (p->nx + 1);
+  SMI_DISPATCH(c, {
+    k2_pad_load<T><<<nblocks(nreal), kB, 0, c->stream>>>((T*)p->real_buf, (const T*)rhs, p->ny, p->nx, c->g, c->px);
+    SMI_CHECK((fft_forward<T>(p, p->real_buf, p->cplx_buf)));
+    k2_cmul<T><<<nblocks(ncplx), kB, 0, c->stream>>>((T*)p->cplx_buf, (const T*)p->ghat, ncplx);
+    if (sizeof(T) == 4)
+      SMI_CHECK_FFT2(hipfftExecC2R(p->inv, (hipfftComplex*)p->cplx_buf, (hipfftReal*)p->real_buf));
+    else
+      SMI_CHECK_FFT2(hipfftExecZ2D(p->inv, (hipfftDoubleComplex*)p->cplx_buf, (hipfftDoubleReal*)p->real_buf));
+    k2_extract<T><<<nblocks((long long)p->ny * p->nx), kB, 0, c->stream>>>((T*)solution, (const T*)p->real_buf, p->ny,
+                                                                          p->nx, c->g, c->px);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}

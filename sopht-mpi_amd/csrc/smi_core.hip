@@ -28,7 +28,8 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   SMI_REQUIRE(ghost >= 1 && ghost <= 8, "smi_ctx_create: ghost size %d must be in [1, 8]", ghost);
   SMI_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "smi_ctx_create: invalid rank %d of %d", rank,
               nranks);
-  SMI_REQUIRE(nz >= 2 * ghost && ny >= 2 * ghost && nx >= 2 * ghost,
+  // nz == 1 (single rank) is the plane of the 2D operators, which ignore the z extent
+  SMI_REQUIRE(((nz == 1 && nranks == 1) || nz >= 2 * ghost) && ny >= 2 * ghost && nx >= 2 * ghost,
               "smi_ctx_create: local grid %d %d %d smaller than 2*ghost", nz, ny, nx);
   SMI_CHECK_HIP(hipSetDevice(device));
   smi_ctx* c = new smi_ctx();

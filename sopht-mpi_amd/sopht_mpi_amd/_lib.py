@@ -88,6 +88,19 @@ SIGNATURES = {
     "smi_prof_enable": [_p, _i],
     "smi_prof_reset": [_p],
     "smi_prof_get": [_p, _i, C.c_char_p, C.POINTER(C.c_int64), _dp, _dp],
+    "smi2d_diffusion_flux": [_p, _p, _p, _d],
+    "smi2d_diffusion_timestep": [_p, _p, _p, _d],
+    "smi2d_advection_timestep_eno3": [_p, _p, _p, _p, _d],
+    "smi2d_outplane_field_curl": [_p, _p, _p, _d],
+    "smi2d_update_vorticity_from_velocity_forcing": [_p, _p, _p, _d],
+    "smi2d_penalise_boundary": [_p, _p, _i, _dp, _dp],
+    "smi2d_set_fixed_val": [_p, _p, _i, _dp],
+    "smi2d_add_fixed_val": [_p, _p, _p, _i, _dp],
+    "smi2d_reduce_max_abs_sum": [_p, _p, _dp],
+    "smi2d_reduce_max": [_p, _p, _dp],
+    "smi2d_poisson_create": [_pp, _p, _p, _d],
+    "smi2d_poisson_destroy": [_p],
+    "smi2d_poisson_solve": [_p, _p, _p],
     "smi_flow_step_ns3d": [_p, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _i, _dp, _dp, _dp, _i, _i],
 }
 _SPECIAL = {

@@ -285,3 +285,4 @@ class UnboundedPoissonSolverMPI3D:
 
 
 __all__ = [n for n in dir() if n.startswith("gen_")] + ["UnboundedPoissonSolverMPI3D", "penalty_factor_tables"]
+from .ops_2d import *  # noqa: F401,F403,E402

@@ -242,3 +242,66 @@ __all__ = [
     "PROC_NULL",
     "DeviceField",
 ]
+
+
+# --------------------------------------------------------------------------- 2D (single rank)
+class _Grid2D(_Grid):
+    def __init__(self, construct):
+        self._c = construct
+        self.coords = np.array([0, 0])
+
+
+class MPIConstruct2D:
+    """utils/mpi_utils_2d.py:9-84.  The 2D path runs on one GPU: 2D grids are a few hundred
+    cells wide, far below what one device holds; more than one rank raises RuntimeError."""
+
+    def __init__(self, grid_size_y, grid_size_x, periodic_domain=False, real_t=np.float64, rank_distribution=None,
+                 world=None):
+        self.grid_dim = 2
+        self.real_t = real_t
+        if periodic_domain:
+            raise NotImplementedError("periodic domains are not supported")
+        self.periodic_domain = False
+        self.world = get_world() if world is None else world
+        self.size, self.rank = self.world.size, self.world.rank
+        if self.size > 1:
+            logger.error("The 2D path is single rank")
+            raise RuntimeError("Invalid domain decomposition")
+        self.rank_distribution = [0, 1] if rank_distribution is None else list(rank_distribution)
+        self.grid_topology = [1, 1]
+        self.global_grid_size = np.array((grid_size_y, grid_size_x))
+        self.local_grid_size = self.global_grid_size.copy()
+        self.grid = _Grid2D(self)
+        self.previous_grid_along = np.array([PROC_NULL, PROC_NULL])
+        self.next_grid_along = np.array([PROC_NULL, PROC_NULL])
+        self._contexts = {}
+
+    def device_context(self, ghost_size):
+        ctx = self._contexts.get(ghost_size)
+        if ctx is None:
+            ny, nx = (int(n) for n in self.local_grid_size)
+            ctx = DeviceContext((1, ny, nx), ghost_size, self.real_t, rank=0, nranks=1, world=self.world)
+            ctx.padded_shape_2d = (ny + 2 * ghost_size, nx + 2 * ghost_size)
+            self._contexts[ghost_size] = ctx
+        return ctx
+
+
+class MPIGhostCommunicator2D:
+    """utils/mpi_utils_2d.py:87-421: with one rank every neighbour is PROC_NULL, nothing moves."""
+
+    def __init__(self, ghost_size, mpi_construct, full_exchange=True):
+        if ghost_size <= 0 or not isinstance(ghost_size, (int, np.integer)):
+            raise ValueError(f"Ghost size {ghost_size} needs to be an integer > 0 for calling ghost communication.")
+        self.ghost_size = int(ghost_size)
+        self.mpi_construct = mpi_construct
+        self.full_exchange = full_exchange
+        self.ctx = mpi_construct.device_context(self.ghost_size)
+
+    def exchange_scalar_field_init(self, local_field):
+        pass
+
+    def exchange_vector_field_init(self, local_vector_field):
+        pass
+
+    def exchange_finalise(self):
+        pass
