@@ -82,11 +82,19 @@ __device__ __forceinline__ void dft8(Cx<T> (&v)[8]) {
   v[7] = e3 - t3;
 }
 
-// Compile-time plan of an L = 2^LG point transform: radix-8 stages, then one radix-4 or
-// radix-2 stage for the remainder.  Every index below folds to constants.
+// Compile-time plan of an L point transform.  The template key LG is log2(L) for powers of
+// two (radix-8 stages, then one radix-4 or radix-2 stage for the remainder) and L itself for
+// L = 64 R with R = 3, 6, 12 (192, 384, 768): three stages of radix 8, R, 8.  Every index
+// below folds to constants.
 template <int LG>
 struct Plan {
-  static constexpr int L = 1 << LG, L8 = L / 8, N8 = LG / 3, REM = LG % 3, NST = N8 + (REM ? 1 : 0);
+  static constexpr bool POW2 = LG < 32;
+  static constexpr int L = POW2 ? (1 << (POW2 ? LG : 0)) : LG, L8 = L / 8;
+  static constexpr int RM = POW2 ? 0 : L / 64;  // middle radix of the 8 x R x 8 plans
+  static_assert(POW2 || (L % 64 == 0 && (RM == 3 || RM == 6 || RM == 12)), "unsupported transform length");
+  static constexpr int N8 = POW2 ? LG / 3 : 0, REM = POW2 ? LG % 3 : 0, NST = POW2 ? N8 + (REM ? 1 : 0) : 3;
+  // threads per sequence: one per work item of 8 points, and 64 for the middle stage of a mixed plan
+  static constexpr int TPS = POW2 ? L8 : (L8 > 64 ? L8 : 64);
   static constexpr int radix(int s) { return s < N8 ? 8 : (1 << REM); }
   static constexpr int ns(int s) {  // product of the radices before stage s
     int n = 1;
@@ -120,11 +128,22 @@ __device__ __forceinline__ int stage_pos(int u, int m) {
 template <typename T, int LG>
 struct Twiddles {
   Cx<T> w[Plan<LG>::NST > 1 ? Plan<LG>::NST : 1][4];
+  const Cx<T>* mid;  // mixed plans: w_{8R}^{q k} = mid[q * mid_step], read from the table at each use
+  int mid_step;
 };
 
 template <typename T, int LG, int S>
 __device__ __forceinline__ void load_stage_tw(Twiddles<T, LG>& tw, int u, const Cx<T>* __restrict__ tw4) {
-  if constexpr (S < Plan<LG>::NST) {
+  if constexpr (!Plan<LG>::POW2) {
+    // middle stage (Ns = 8): w_{8R}^{q k} = tw4[32 q k], k = j mod 8; last stage (Ns = L/8): w_L^u and
+    // its 2nd and 4th powers (idle lanes u >= L/8 read a valid entry)
+    const int ul = u < Plan<LG>::L8 ? u : 0;
+    tw.mid = tw4;
+    tw.mid_step = 32 * (u & 7);
+    tw.w[2][0] = tw4[4 * ul];
+    tw.w[2][1] = tw4[8 * ul];
+    tw.w[2][2] = tw4[16 * ul];
+  } else if constexpr (S < Plan<LG>::NST) {
     if constexpr (S > 0) {
       constexpr int R = Plan<LG>::radix(S), Ns = Plan<LG>::ns(S), L = Plan<LG>::L, L8 = Plan<LG>::L8;
       if (R == 8) {
@@ -200,11 +219,12 @@ constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per 
 #endif
 // Sequences per tile.  Column passes want >= 16 (f32) / 8 (f64) so that every row of the tile
 // is a whole 128-byte line; TS * L / 8 threads, at most 1024.
-constexpr int tile_seqs(int L, bool f32, bool rows) {
+constexpr int tile_seqs(int L, int tps, bool f32, bool rows) {
   int want = rows ? 4 : (f32 ? SMI_FFT_COLS_F32 : 8);
-  int ts = 2048 / L > want ? 2048 / L : want;
-  if (ts * L / 8 > kMaxThreads) ts = kMaxThreads * 8 / L;
-  return ts < 1 ? 1 : ts;
+  int ts = want;
+  while (ts * L < 2048) ts *= 2;
+  while (ts > 1 && ts * tps > kMaxThreads) ts /= 2;
+  return ts;
 }
 
 // LDS tile layouts.  Column passes: lds[pos * TSP + t], lanes run along the sequences of the
@@ -266,8 +286,125 @@ __device__ __forceinline__ void fft_run_from(Cx<T> (&v)[8], TileSel<T, PP>& sel,
   }
 }
 template <int SIGN, bool FIRST_FROM_LDS, int LG, typename LAY, typename T, bool PP>
+__device__ __forceinline__ void fft_run(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u, const Twiddles<T, LG>& tw);
+
+// ---- mixed 8 x R x 8 plans ------------------------------------------------------------
+template <int SIGN, typename T>
+__device__ __forceinline__ void dft3(Cx<T>& a, Cx<T>& b, Cx<T>& c) {
+  const T h = (T)(SIGN * 0.86602540378443864676);  // SIGN sin(2 pi / 3)
+  const Cx<T> t = b + c, d = b - c, m{a.x - (T)0.5 * t.x, a.y - (T)0.5 * t.y};
+  const Cx<T> id{-h * d.y, h * d.x};  // i h d
+  a = a + t;
+  b = m + id;
+  c = m - id;
+}
+
+// x[0..R-1] -> DFT_R in place (natural order in, natural order out), R = 3, 6, 12
+template <int SIGN, int R, typename T>
+__device__ __forceinline__ void dft_mid(Cx<T> (&x)[12]) {
+  if constexpr (R == 3) {
+    dft3<SIGN>(x[0], x[1], x[2]);
+  } else if constexpr (R == 6) {
+    // n = 2 n1 + n2, k = k1 + 3 k2
+    Cx<T> e0 = x[0], e1 = x[2], e2 = x[4], o0 = x[1], o1 = x[3], o2 = x[5];
+    dft3<SIGN>(e0, e1, e2);
+    dft3<SIGN>(o0, o1, o2);
+    const T h = (T)(SIGN * 0.86602540378443864676);
+    o1 = o1 * Cx<T>{(T)0.5, h};    // w6
+    o2 = o2 * Cx<T>{(T)-0.5, h};   // w6^2
+    x[0] = e0 + o0;
+    x[3] = e0 - o0;
+    x[1] = e1 + o1;
+    x[4] = e1 - o1;
+    x[2] = e2 + o2;
+    x[5] = e2 - o2;
+  } else {
+    // n = 4 n1 + n2, k = k1 + 3 k2: four 3-point transforms, twiddles w12^{n2 k1}, three 4-point ones
+    Cx<T> a[4][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+      a[n2][0] = x[n2];
+      a[n2][1] = x[4 + n2];
+      a[n2][2] = x[8 + n2];
+      dft3<SIGN>(a[n2][0], a[n2][1], a[n2][2]);
+    }
+    const T s = (T)SIGN, c30 = (T)0.86602540378443864676;
+    a[1][1] = a[1][1] * Cx<T>{c30, s * (T)0.5};          // w12
+    a[1][2] = a[1][2] * Cx<T>{(T)0.5, s * c30};          // w12^2
+    a[2][1] = a[2][1] * Cx<T>{(T)0.5, s * c30};          // w12^2
+    a[2][2] = a[2][2] * Cx<T>{(T)-0.5, s * c30};         // w12^4
+    a[3][1] = mul_si<SIGN>(a[3][1]);                     // w12^3 = SIGN i
+    a[3][2] = Cx<T>{-a[3][2].x, -a[3][2].y};             // w12^6 = -1
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+      dft4<SIGN>(a[0][k1], a[1][k1], a[2][k1], a[3][k1]);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) x[k1 + 3 * k2] = a[k2][k1];
+    }
+  }
+}
+
+// Radix-8 stage on work items u < L/8 (no twiddles: Ns = 1), exchange, radix-R stage on
+// items j < 64 (item j owns j + 64 r, twiddle w_{8R}^{r (j mod 8)}, writes (j - k) R + k + 8 q),
+// exchange, radix-8 stage with twiddles w_L^{m u}.  Every lane takes both barriers.
+template <int SIGN, int LG, typename LAY, typename T, bool PP>
+__device__ __forceinline__ void fft_run_mixed(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u,
+                                              const Twiddles<T, LG>& tw) {
+  constexpr int L8 = Plan<LG>::L8, R = Plan<LG>::RM;
+  const bool a8 = u < L8, am = u < 64;
+  if (a8) dft8<SIGN>(v);
+  Cx<T>* w = sel.next();
+  if (a8) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) w[LAY::idx(u * 8 + m, t)] = v[m];
+  }
+  __syncthreads();
+  Cx<T> x[12];
+  if (am) {
+    const Cx<T>* r = sel.cur;
+#pragma unroll
+    for (int q = 0; q < R; ++q) x[q] = r[LAY::idx(u + 64 * q, t)];
+  }
+  sel.after_read();
+  w = sel.next();
+  if (am) {
+    // table values rather than running powers: eleven chained products would cost accuracy
+#pragma unroll
+    for (int q = 1; q < R; ++q) x[q] = x[q] * sgn<SIGN>(tw.mid[q * tw.mid_step]);
+    dft_mid<SIGN, R>(x);
+    const int k = u & 7;
+#pragma unroll
+    for (int q = 0; q < R; ++q) w[LAY::idx((u - k) * R + k + 8 * q, t)] = x[q];
+  }
+  __syncthreads();
+  if (a8) {
+    const Cx<T>* r = sel.cur;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = r[LAY::idx(u + m * L8, t)];
+  }
+  sel.after_read();
+  if (a8) {
+    const Cx<T> w1 = sgn<SIGN>(tw.w[2][0]), w2 = sgn<SIGN>(tw.w[2][1]), w4 = sgn<SIGN>(tw.w[2][2]);
+    const Cx<T> w3 = w1 * w2, w5 = w4 * w1, w6 = w4 * w2, w7 = w4 * w3;
+    v[1] = v[1] * w1;
+    v[2] = v[2] * w2;
+    v[3] = v[3] * w3;
+    v[4] = v[4] * w4;
+    v[5] = v[5] * w5;
+    v[6] = v[6] * w6;
+    v[7] = v[7] * w7;
+    dft8<SIGN>(v);
+  }
+}
+
+template <int SIGN, bool FIRST_FROM_LDS, int LG, typename LAY, typename T, bool PP>
 __device__ __forceinline__ void fft_run(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u, const Twiddles<T, LG>& tw) {
-  fft_run_from<SIGN, FIRST_FROM_LDS, LG, LAY, 0>(v, sel, t, u, tw);
+  if constexpr (Plan<LG>::POW2) {
+    fft_run_from<SIGN, FIRST_FROM_LDS, LG, LAY, 0>(v, sel, t, u, tw);
+  } else {
+    static_assert(!FIRST_FROM_LDS, "mixed plans take their input in registers");
+    fft_run_mixed<SIGN, LG, LAY>(v, sel, t, u, tw);
+  }
 }
 
 // w * exp(-i pi m / 8): the zero-padding twiddle exp(-i pi n / L) of element n = u + m L/8 is
@@ -313,7 +450,8 @@ __device__ __forceinline__ size_t rowB(const PGeo& G, int c, int z, int kyp) {
 template <typename T, int LG, bool ROWS>
 struct TileCfg {
   static constexpr int L = Plan<LG>::L, L8 = Plan<LG>::L8;
-  static constexpr int TS = tile_seqs(L, sizeof(T) == 4, ROWS), NT = TS * L8;
+  static constexpr int TPS = Plan<LG>::TPS;
+  static constexpr int TS = tile_seqs(L, TPS, sizeof(T) == 4, ROWS), NT = TS * TPS;
   static constexpr int PITCH = L + L / 8 + 1;                            // row layout
   static constexpr int ELEMS = ROWS ? TS * PITCH : L * TS;               // one tile
   static constexpr bool PP = 2 * ELEMS * sizeof(Cx<T>) <= kLdsBudget;    // room for two tiles
@@ -327,12 +465,13 @@ struct TileCfg {
   constexpr int L = Cfg::L, L8 = Cfg::L8, TS = Cfg::TS;                                \
   extern __shared__ char smem[];                                                       \
   TileSel<T, Cfg::PP> sel(reinterpret_cast<Cx<T>*>(smem), Cfg::ELEMS);                 \
-  const int t = ROWS ? threadIdx.x / L8 : threadIdx.x & (TS - 1);                      \
-  const int u = ROWS ? threadIdx.x & (L8 - 1) : threadIdx.x / TS;                      \
+  const int t = ROWS ? threadIdx.x / Cfg::TPS : threadIdx.x & (TS - 1);                \
+  const int u = ROWS ? threadIdx.x % Cfg::TPS : threadIdx.x / TS;                      \
+  const bool item = Plan<LG>::POW2 || u < L8; /* lanes beyond the work items only serve the middle stage */ \
   Twiddles<T, LG> tw;                                                                  \
   load_stage_tw<T, LG, 0>(tw, u, tw4);                                                 \
   const Cx<T> wu = tw4[2 * u]; /* exp(-i pi u / L) */                                  \
-  (void)L; (void)wu;
+  (void)L; (void)wu; (void)item;
 
 // Addressing in the column kernels: every global access is (workgroup-uniform 64-bit
 // pointer that absorbs the element index m) [32-bit per-thread offset].  The per-thread part
@@ -349,7 +488,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = G.c0 + blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
-  const bool ok = TS <= 16 || col < G.KXL;
+  const bool ok = (TS <= 16 || col < G.KXL) && item;
   const Cx<T>* src = in + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
   Cx<T>* dst = out + rowB(G, c, z, 0);
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
@@ -376,7 +515,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int c = G.c0 + blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
-  const bool ok = TS <= 16 || col < G.KXL;
+  const bool ok = (TS <= 16 || col < G.KXL) && item;
   const Cx<T>* src = in + rowB(G, c, z, 0);
   Cx<T>* dst = out + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
@@ -415,7 +554,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
   const int kyc = blockIdx.y, col = blockIdx.x * TS + t;
-  const bool ok = TS <= 16 || col < G.KXL;
+  const bool ok = (TS <= 16 || col < G.KXL) && item;
   const int ZB = 1 << G.zb_shift;
   const size_t blk = (size_t)(2 * G.ny) * ZB * G.KXP;  // elements per z block of one component
   const size_t cstride = (size_t)(G.nz >> G.zb_shift) * blk;
@@ -519,7 +658,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
-  const bool ok = y < G.ny;
+  const bool ok = y < G.ny && item;
   const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXP;
   const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
@@ -533,14 +672,16 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
     fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
     Cx<T>* z = sel.next();
+    if (item) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) z[Lay::idx(u + m * L8, t)] = v[m];
+      for (int m = 0; m < 8; ++m) z[Lay::idx(u + m * L8, t)] = v[m];
+    }
     __syncthreads();
     if (ok) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int k = u + m * L8;
-        const int kp = parity ? L - 1 - k : (L - k) & (L - 1);
+        const int kp = parity ? L - 1 - k : (k ? L - k : 0);
         const Cx<T> a = v[m], b = conj(z[Lay::idx(kp, t)]);
         Cx<T> w = mul_c16(wu, m);  // exp(-i pi k / L)
         if (parity) w = w * w1;
@@ -567,7 +708,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
-  const bool ok = y < G.ny;
+  const bool ok = y < G.ny && item;
   T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXP;
   const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
@@ -624,6 +765,12 @@ __global__ void __launch_bounds__(kThreads) k_fold_green(T* __restrict__ green, 
 }
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+int ilog2(int n);
+// template key of the plan for an n-point transform (see Plan): log2(n), n itself for 192 / 384 / 768, 0 if none
+int plan_key(int n) {
+  if (is_pow2(n) && n >= 8 && n <= 2048) return ilog2(n);
+  return (n == 192 || n == 384 || n == 768) ? n : 0;
+}
 
 int ilog2(int n) {
   int s = 0;
@@ -639,7 +786,7 @@ int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per
 
 struct PrunedState {
   PGeo G;
-  int lgx, lgy, lgz;  // log2 of the transform lengths nx/2, ny, nz
+  int lgx, lgy, lgz;  // plan keys of the transform lengths nx/2, ny, nz
   void* tw[3] = {nullptr, nullptr, nullptr};  // x, y, z twiddle tables (4L complex each)
   void* bufA = nullptr;
   void* bufT = nullptr;  // == bufA on a single rank
@@ -689,8 +836,10 @@ static int set_lds(const void* fn, size_t bytes) {
 
 int smi_pruned_create(smi_poisson* p) {
   smi_ctx* c = p->ctx;
-  SMI_REQUIRE(is_pow2(p->gnx) && is_pow2(p->gny) && is_pow2(p->gnz) && p->gnx >= 16 && p->gny >= 8 && p->gnz >= 8,
-              "SMI_POISSON_PRUNED needs power of two grid sizes with nx >= 16, ny >= 8, nz >= 8 (got %d %d %d)",
+  SMI_REQUIRE(p->gnx % 2 == 0 && plan_key(p->gnx / 2) && plan_key(p->gny) && plan_key(p->gnz) && p->gnx >= 16 &&
+                  p->gny >= 8 && p->gnz >= 8,
+              "SMI_POISSON_PRUNED needs transform lengths nx/2, ny, nz that are powers of two or 192, 384, 768, "
+              "with nx >= 16, ny >= 8, nz >= 8 (got %d %d %d); power of two grid sizes always qualify",
               p->gnz, p->gny, p->gnx);
   SMI_REQUIRE(p->gnx <= 4096 && p->gny <= 2048 && p->gnz <= 2048, "SMI_POISSON_PRUNED: grid too large");
   PrunedState* s = new PrunedState();
@@ -706,10 +855,11 @@ int smi_pruned_create(smi_poisson* p) {
   G.KXL = (G.nx + 1 + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
   // z blocks of at most 16 planes and at most nz / 8 (one work item's elements share z % ZB)
-  G.zb_shift = G.nz >= 128 ? 4 : ilog2(G.nz) - 3;
-  s->lgx = ilog2(G.nx / 2);
-  s->lgy = ilog2(G.ny);
-  s->lgz = ilog2(G.nz);
+  G.zb_shift = 0;  // largest power of two <= 16 that divides nz / 8
+  while (G.zb_shift < 4 && (G.nz / 8) % (2 << G.zb_shift) == 0) ++G.zb_shift;
+  s->lgx = plan_key(G.nx / 2);
+  s->lgy = plan_key(G.ny);
+  s->lgz = plan_key(G.nz);
   const size_t cs = 2 * smi_elem_size(c);
   const size_t nA = (size_t)G.P * G.nc * G.nzl * G.ny * G.KXP;
   const size_t nB = (size_t)G.nc * G.nz * 2 * G.ny * G.KXP;
@@ -819,7 +969,7 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, voi
   switch (lg) {                                                                                 \
     LG_CASE(3, __VA_ARGS__) LG_CASE(4, __VA_ARGS__) LG_CASE(5, __VA_ARGS__) LG_CASE(6, __VA_ARGS__) \
     LG_CASE(7, __VA_ARGS__) LG_CASE(8, __VA_ARGS__) LG_CASE(9, __VA_ARGS__) LG_CASE(10, __VA_ARGS__) \
-    LG_CASE(11, __VA_ARGS__)                                                                    \
+    LG_CASE(11, __VA_ARGS__) LG_CASE(192, __VA_ARGS__) LG_CASE(384, __VA_ARGS__) LG_CASE(768, __VA_ARGS__) \
     default: smi_set_error("unsupported transform length 2^%d", lg); return 1;                  \
   }
 

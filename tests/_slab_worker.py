@@ -25,9 +25,9 @@ from oracle import immersed_boundary as oib  # noqa: E402
 world = get_world()
 rank, size = world.rank, world.size
 real_t = np.float32
-n = (32, 16, 32)
 flow_type = sys.argv[1] if len(sys.argv) > 1 else "navier_stokes"
 fused = (sys.argv[2] == "fused") if len(sys.argv) > 2 else True
+n = tuple(int(v) for v in sys.argv[3].split("x")) if len(sys.argv) > 3 else (32, 16, 32)
 kw = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, flow_type=flow_type, real_t=real_t,
           with_free_stream_flow=True, filter_vorticity=True, filter_setting_dict={"order": 1, "type": "multiplicative"})
 gpu = UnboundedFlowSimulator3D(fused_step=fused, **kw)

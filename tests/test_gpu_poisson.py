@@ -32,7 +32,10 @@ def _solver(smi, ctx, shape, x_range, real_t, backend):
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
 @pytest.mark.parametrize("shape,g", [((8, 8, 8), 2), ((16, 16, 16), 2), ((8, 16, 32), 1), ((32, 32, 32), 2),
-                                     ((8, 12, 16), 2)])
+                                     ((8, 12, 16), 2),
+                                     # transform lengths 192, 384, 768 (radix 8 x R x 8 plans) on each axis
+                                     ((8, 192, 384), 2), ((384, 8, 768), 2), ((8, 384, 16), 2), ((192, 8, 16), 2),
+                                     ((768, 8, 16), 2), ((8, 768, 16), 2), ((8, 8, 1536), 2)])
 def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
     rng = np.random.default_rng(7)
     ctx = make_ctx(smi, shape, g, real_t)
@@ -47,7 +50,9 @@ def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
     oracle.vector_field_solve(want, rhs, g)
     got = dsol.get()
     inner = (slice(None),) + (slice(g, -g),) * 3
-    assert_close(got[inner], want[inner], real_t, factor=2.0, what=f"poisson[{backend}]")
+    # 3072-point padded rows in f32: both sides carry a few 1e-5 of rounding at this length
+    factor = 2.0 if max(shape) < 1024 else 4.0
+    assert_close(got[inner], want[inner], real_t, factor=factor, what=f"poisson[{backend}]")
     mask = np.ones(got.shape, dtype=bool)
     mask[inner] = False
     assert np.array_equal(got[mask], sol0[mask]), "solution ghost cells were modified"
@@ -55,7 +60,7 @@ def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
     # scalar entry point, third component
     dsol1 = ctx.field()
     smi._lib.call("smi_poisson_solve", h, dsol1.ptr, drhs[2].ptr)
-    assert_close(dsol1.get()[inner[1:]], want[2][inner[1:]], real_t, factor=2.0, what="scalar solve")
+    assert_close(dsol1.get()[inner[1:]], want[2][inner[1:]], real_t, factor=factor, what="scalar solve")
     smi._lib.call("smi_poisson_destroy", h)
 
 

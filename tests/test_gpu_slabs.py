@@ -12,19 +12,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("nranks,flow_type,mode", [
-    (2, "navier_stokes", "fused"),
-    (4, "navier_stokes", "unfused"),
-    (2, "navier_stokes_with_forcing", "fused"),
-    (4, "navier_stokes_with_forcing", "fused"),
+@pytest.mark.parametrize("nranks,flow_type,mode,grid", [
+    (2, "navier_stokes", "fused", "32x16x32"),
+    (4, "navier_stokes", "unfused", "32x16x32"),
+    (2, "navier_stokes_with_forcing", "fused", "32x16x32"),
+    (4, "navier_stokes_with_forcing", "fused", "32x16x32"),
+    (4, "navier_stokes", "fused", "192x16x32"),   # a 192-point (radix 8 x 3 x 8) transform across the slabs
 ])
-def test_slab_flow_step_matches_oracle(nranks, flow_type, mode):
+def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env["SOPHT_MI_TRANSPORT"] = "host"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + nranks),
-           os.path.join(ROOT, "tests", "_slab_worker.py"), flow_type, mode]
+           os.path.join(ROOT, "tests", "_slab_worker.py"), flow_type, mode, grid]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     for r in range(nranks):
