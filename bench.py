@@ -179,7 +179,7 @@ def main():
             "workload": f"3D {n}^3 navier_stokes flow step (rotational advection + diffusion + penalise + "
                         "3 unbounded Poisson solves + curl), ghost 2, seeded Gaussian-blob vorticity",
             "grid": [n, n, n],
-            "partition": "1 GPU" if args.gpus == 1 else f"{args.gpus} z-slabs, RCCL",
+            "partition": "1 GPU" if args.gpus == 1 else f"{args.gpus} z-slabs, transport {sim.ctx.transport}",
             "poisson_backend": sim.unbounded_poisson_solver.backend,
             "step_bytes_model": "lower bound, 660 B per grid point per step",
             "step_hbm_frac": MIN_BYTES_PER_POINT_STEP * value / args.gpus / 1e9 / HBM_PEAK_GBS,

@@ -100,7 +100,16 @@ class MPIConstruct3D:
                 call("smi_device_count", C.byref(ndev))
                 mode = os.environ.get("SOPHT_MI_TRANSPORT", "rccl" if ndev.value >= self.size else "host")
                 if mode == "rccl":
-                    ctx.init_rccl()
+                    # every rank must end up on the same transport: agree on the outcome
+                    try:
+                        ctx.init_rccl()
+                        ok = 1.0
+                    except _lib.SophtMIError as exc:
+                        logger.error(f"rank {self.rank}: RCCL initialisation failed ({exc})")
+                        ok = 0.0
+                    if self.world.allreduce(ok, "min") < 1.0:
+                        logger.error("falling back to the host-staged transport on all ranks")
+                        ctx.init_host_staged()
                 else:
                     ctx.init_host_staged()
             self._contexts[ghost_size] = ctx
