@@ -108,6 +108,7 @@ __device__ __forceinline__ void store4(T* p, const Vec4<T>& v) {
 // internal cross-TU helpers
 int smi_halo_exchange_impl(smi_ctx* ctx, void* field, int ncomp);
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
+int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
 int smi_update_vorticity_into_impl(smi_ctx* c, void* out, const void* vorticity, void* forcing, double prefactor);
 // true when this context has neighbours to exchange with

@@ -715,6 +715,77 @@ __global__ void __launch_bounds__(kBlock) k_filter_pass(T* __restrict__ flux, co
   flux[i] = v;
 }
 
+// One-pass form of the order-1 multiplicative filter: out = f - Lz(Ly(Lx f)), where each
+// directional pass L_a g = 0.25 (-g(+1) - g(-1) + 2 g) is taken on D and is 0 elsewhere, exactly
+// as the three passes above leave it (so the intermediate fields vanish outside D when the next
+// pass reads them).  F2 = Ly(Lx f) of a plane only needs f of that plane, so the kernel marches
+// along z with F2 of the planes behind, at and ahead in registers.  Planes one past a rank
+// boundary count as inside for the intermediate fields (there the neighbour rank computes them
+// from the same exchanged values); [zlo_e, zhi_e] is that extended range.
+template <typename T, int V>
+__global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, const T* __restrict__ f, Geo G,
+                                                        int zchunk, int zlo_e, int zhi_e) {
+  const Blk B = xcd_block<false>();
+  long long q;
+  int y, x0;
+  if (!lane_pos<V>(G, B, q, y, x0)) return;
+  f += (long long)B.z * G.vol + q;
+  out += (long long)B.z * G.vol + q;
+  bool xc[V], anyx = false;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    xc[e] = in_core(x0 + e, G.px, G.g);
+    anyx |= xc[e];
+  }
+  const bool yc = in_core(y, G.py, G.g);
+  const bool ycm = in_core(y - 1, G.py, G.g), ycp = in_core(y + 1, G.py, G.g);
+  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
+  if (!(yc && anyx) || zs > ze) {
+    for (int z = z0; z < z1; ++z) st<T, V>(out + z * G.plane, ld<T, V>(f + z * G.plane));
+    return;
+  }
+  // Lx f of one row of plane zp (masked to the row's cells inside D)
+  auto lx_row = [&](const T* row, bool row_in_core) {
+    Pack<T, V> r = zero_pack<T, V>();
+    if (!row_in_core) return r;
+    const Pack<T, V> c = ld<T, V>(row);
+    const T xm = row[-1], xp = row[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const T left = e == 0 ? xm : c.v[e - 1], right = e == V - 1 ? xp : c.v[e + 1];
+      r.v[e] = xc[e] ? T(0.25) * (-right - left + T(2) * c.v[e]) : T(0);
+    }
+    return r;
+  };
+  // F2 = Ly(Lx f) of this lane's cells in plane zp
+  auto f2_plane = [&](int zp) {
+    Pack<T, V> r = zero_pack<T, V>();
+    if (zp < zlo_e || zp > zhi_e) return r;
+    const T* pc = f + zp * G.plane;
+    const Pack<T, V> a = lx_row(pc - G.px, ycm), b = lx_row(pc, true), c = lx_row(pc + G.px, ycp);
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = xc[e] ? T(0.25) * (-c.v[e] - a.v[e] + T(2) * b.v[e]) : T(0);
+    return r;
+  };
+  for (int z = z0; z < zs; ++z) st<T, V>(out + z * G.plane, ld<T, V>(f + z * G.plane));
+  Pack<T, V> prev = f2_plane(zs - 1), cur = f2_plane(zs);
+  for (int z = zs; z <= ze; ++z) {
+    const Pack<T, V> nxt = f2_plane(z + 1);
+    const Pack<T, V> fc = ld<T, V>(f + z * G.plane);
+    Pack<T, V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const T flux = xc[e] ? T(0.25) * (-nxt.v[e] - prev.v[e] + T(2) * cur.v[e]) : T(0);
+      o.v[e] = fc.v[e] - flux;
+    }
+    st<T, V>(out + z * G.plane, o);
+    prev = cur;
+    cur = nxt;
+  }
+  for (int z = ze + 1; z < z1; ++z) st<T, V>(out + z * G.plane, ld<T, V>(f + z * G.plane));
+}
+
 // zero the outer (g + width) layers next to physical faces (zero_bands of the wrappers)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_zero_bands(T* __restrict__ f, Geo G, int w, int zlo, int zhi) {
@@ -961,6 +1032,26 @@ static int filter_pass(smi_ctx* c, const Geo& G, int axis, T* flux, T* src) {
   return 0;
 }
 
+// out = in - Lz(Ly(Lx in)): the multiplicative filter of order 1 in one pass per component
+int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp) {
+  SMI_REQUIRE(out != in, "filter: output and input must not alias");
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, in, ncomp));
+  Geo G = make_geo(c);
+  const int zlo_e = G.zlo_c - (c->phys_zlo ? 0 : 1), zhi_e = G.zhi_c + (c->phys_zhi ? 0 : 1);
+  SmiProfScope prof(c, PROF_FILTER, 2.0 * ncomp * smi_S(c));
+  SMI_DISPATCH(c, {
+    if (vec_ok<T>(c, out, in)) {
+      LaunchShape s = plan<4>(c, ncomp);
+      k_filter_fused<T, 4><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e);
+    } else {
+      LaunchShape s = plan<1>(c, ncomp);
+      k_filter_fused<T, 1><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e);
+    }
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* filter_flux_buffer,
                                     void* field_buffer, int order, int filter_type) {
   SMI_REQUIRE(c && field && filter_flux_buffer && field_buffer && ncomp >= 1, "smi_laplacian_filter: bad argument");
@@ -968,6 +1059,16 @@ extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* fi
   SMI_REQUIRE(filter_type == SMI_FILTER_MULTIPLICATIVE || filter_type == SMI_FILTER_CONVOLUTION,
               "Invalid filter type");
   Geo G = make_geo(c);
+  if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1) {
+    // one fused pass into the scratch field, then back (the scratch fields hold one component)
+    const size_t stride = c->vol * smi_elem_size(c);
+    for (int k = 0; k < ncomp; ++k) {
+      void* fk = (char*)field + (size_t)k * stride;
+      SMI_CHECK(smi_filter_apply_impl(c, field_buffer, fk, 1));
+      SMI_CHECK(smi_elementwise_copy(c, fk, field_buffer, 1));
+    }
+    return 0;
+  }
   SmiProfScope prof(c, PROF_FILTER, 2.0 * ncomp * smi_S(c));
   SMI_DISPATCH(c, {
     T* flux = (T*)filter_flux_buffer;

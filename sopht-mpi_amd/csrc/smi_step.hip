@@ -24,11 +24,18 @@ extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, v
   // advected vorticity w + dt/(2dx) curl(u x w) lands in buffer_vector (u x w itself only ever
   // exists in registers) and the diffusion step brings it back into vorticity.
   SMI_CHECK(smi_advect_vorticity_impl(c, buffer_vector, velocity, vorticity, pref_curl));
-  SMI_CHECK(smi_diffusion_apply_impl(c, vorticity, buffer_vector, pref_diff, 3));
-  if (filter_order > 0) {
-    size_t stride = c->vol * smi_elem_size(c);
-    SMI_CHECK(smi_laplacian_filter(c, vorticity, 3, buffer_vector, (char*)buffer_vector + stride, filter_order,
-                                   filter_type));
+  if (filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE) {
+    // the common filter setting runs as one more single pass: diffuse into the (still dead) stream
+    // function array, filter from there back into vorticity
+    SMI_CHECK(smi_diffusion_apply_impl(c, stream_func, buffer_vector, pref_diff, 3));
+    SMI_CHECK(smi_filter_apply_impl(c, vorticity, stream_func, 3));
+  } else {
+    SMI_CHECK(smi_diffusion_apply_impl(c, vorticity, buffer_vector, pref_diff, 3));
+    if (filter_order > 0) {
+      size_t stride = c->vol * smi_elem_size(c);
+      SMI_CHECK(smi_laplacian_filter(c, vorticity, 3, buffer_vector, (char*)buffer_vector + stride, filter_order,
+                                     filter_type));
+    }
   }
   SMI_CHECK(smi_penalise_boundary(c, vorticity, 3, penalty_width, fac_lo, fac_hi));
   SMI_CHECK(smi_poisson_vector_solve(p, stream_func, vorticity));
