@@ -246,6 +246,18 @@ int smi2d_reduce_max(smi_ctx* ctx, const void* field, double* out);
 int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* ctx, const void* greens_host, double dx);
 int smi2d_poisson_destroy(smi_poisson2d* p);
 int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void* rhs);
+/* immersed_boundary_ops/EulerianLagrangianGridCommunicatorMPI2D.py:116-520: support (2,4,4,M) and
+ * nearest index (2,M) of the nodes, delta-function weights (4,4,M), Eulerian -> Lagrangian
+ * interpolation, Lagrangian -> Eulerian spreading (ghost_sum != 0: followed by the ghost sum of
+ * :521-652, which on one rank clears the ghost cells). */
+int smi2d_ib_support(smi_ctx* ctx, void* support, void* nearest_index, const void* lag_positions,
+                     int64_t m, double dx, double coord_shift);
+int smi2d_ib_weights(smi_ctx* ctx, void* weights, void* support, int64_t m, double dx,
+                     int kernel_type);
+int smi2d_ib_interpolate(smi_ctx* ctx, void* lag_field, const void* eul_field, const void* weights,
+                         const void* nearest_index, int64_t m, int ncomp, double dx);
+int smi2d_ib_spread(smi_ctx* ctx, void* eul_field, const void* lag_field, const void* weights,
+                    const void* nearest_index, int64_t m, int ncomp, int ghost_sum);
 
 #ifdef __cplusplus
 }

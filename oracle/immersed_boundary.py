@@ -93,13 +93,14 @@ def lagrangian_to_eulerian_grid_interpolation(eul_field, lag_field, weights, nea
                 eul_field[(c,) + win] += lag_field[c, i] * weights[..., i]
 
 
-def clear_ghost_cells(field, g):
-    """:786-792 for the last ``dim`` axes of ``field`` (dim inferred: 2D if ndim==2)."""
+def clear_ghost_cells(field, g, grid_dim=3):
+    """:786-792 (2D: EulerianLagrangianGridCommunicatorMPI2D.py:646-652) for the last ``grid_dim``
+    axes of ``field``; a leading component axis is left alone."""
     field[..., :g] = 0
     field[..., -g:] = 0
     field[..., :g, :] = 0
     field[..., -g:, :] = 0
-    if field.ndim >= 3:
+    if grid_dim == 3:
         field[..., :g, :, :] = 0
         field[..., -g:, :, :] = 0
 
@@ -166,7 +167,7 @@ class VirtualBoundaryForcing:
         lagrangian_to_eulerian_grid_interpolation(
             eul_forcing, self.lag_forcing, self.weights, self.nearest_index, self.w
         )
-        clear_ghost_cells(eul_forcing, self.g)
+        clear_ghost_cells(eul_forcing, self.g, self.grid_dim)
 
     def time_step(self, dt):
         """:452-459."""

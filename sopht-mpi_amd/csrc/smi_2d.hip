@@ -410,3 +410,208 @@ extern "C" int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void*
   SMI_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- immersed boundary in 2D (EulerianLagrangianGridCommunicatorMPI2D.py:116-520) -------------
+// Sixteen lanes per Lagrangian node: the 4 x 4 delta-function window, lane = (dy << 2) | dx.
+// Lagrangian data are float64, the Eulerian grid is the context's real type.
+namespace {
+
+constexpr int kW2 = 2;  // interp_kernel_width (the reference asserts 2)
+
+__device__ __forceinline__ double py_floordiv2(double a, double b) {
+  double mod = fmod(a, b);
+  double div = (a - mod) / b;
+  if (mod != 0.0 && ((b < 0.0) != (mod < 0.0))) div -= 1.0;
+  double fl;
+  if (div != 0.0) {
+    fl = floor(div);
+    if (div - fl > 0.5) fl += 1.0;
+  } else {
+    fl = copysign(0.0, a / b);
+  }
+  return fl;
+}
+
+struct Ib2 {
+  int py, px, g;
+  long long n;
+  double dx, shift;
+  long long ls;  // local substart coordinate shift = -ghost on the single rank
+};
+
+Ib2 make_ib2(const smi_ctx* c, double dx, double shift) {
+  return Ib2{c->py, c->px, c->g, (long long)c->py * c->px, dx, shift, -(long long)c->g};
+}
+
+struct Delta2 {
+  double c_cos, half_pi, c_pes;
+};
+// constants typed as the reference's njit closures type them (real_t values used in float64 arithmetic)
+Delta2 make_delta2(const smi_ctx* c, double dx) {
+  Delta2 d;
+  d.c_cos = (0.25 / dx) * (0.25 / dx);
+  d.half_pi = 0.5 * M_PI;
+  d.c_pes = (0.125 / dx) * (0.125 / dx);
+  if (c->dtype == SMI_F32) {
+    d.c_cos = (double)(float)d.c_cos;
+    d.half_pi = (double)(float)d.half_pi;
+    d.c_pes = -d.c_pes;  // flags rounding of the Peskin weights to single precision
+  }
+  return d;
+}
+
+__device__ __forceinline__ double peskin2_1d(double r) {
+  double a = (r < 1.0) ? (3.0 - 2 * r + sqrt(fabs(1 + 4 * r - 4 * r * r))) : 0.0;
+  double b = (r >= 1.0 && r < 2.0) ? (5.0 - 2 * r - sqrt(fabs(-7 + 12 * r - 4 * r * r))) : 0.0;
+  return a + b;
+}
+
+__global__ void __launch_bounds__(256) k2_ib_support(double* __restrict__ support, long long* __restrict__ index,
+                                                     const double* __restrict__ pos, long long m, Ib2 G) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long node = gid >> 4;
+  if (node >= m) return;
+  const int lane = (int)(gid & 15), ox = (lane & 3) - kW2 + 1, oy = (lane >> 2) - kW2 + 1;
+  const double X = pos[node], Y = pos[m + node];
+  const long long ix = (long long)py_floordiv2(X - G.shift, G.dx) - G.ls;
+  const long long iy = (long long)py_floordiv2(Y - G.shift, G.dx) - G.ls;
+  if (lane == 0) {
+    index[node] = ix;
+    index[m + node] = iy;
+  }
+  const long long cell = (long long)lane * m + node;  // support[c][dy][dx][node]
+  support[cell] = (double)(ix + ox + G.ls) * G.dx + G.shift - X;
+  support[16 * m + cell] = (double)(iy + oy + G.ls) * G.dx + G.shift - Y;
+}
+
+__global__ void __launch_bounds__(256) k2_ib_weights(double* __restrict__ weights, double* __restrict__ support,
+                                                     long long m, double dx, int kernel_type, Delta2 dc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 16 * m) return;
+  double sx = support[i], sy = support[16 * m + i], w;
+  if (kernel_type == SMI_DELTA_COSINE) {
+    sx /= dx;
+    sy /= dx;
+    w = dc.c_cos * (1.0 + cos(dc.half_pi * sx)) * (1.0 + cos(dc.half_pi * sy));
+  } else {
+    sx = fabs(sx) / dx;
+    sy = fabs(sy) / dx;
+    w = fabs(dc.c_pes) * peskin2_1d(sx) * peskin2_1d(sy);
+    if (dc.c_pes < 0.0) w = (double)(float)w;
+  }
+  support[i] = sx;  // the reference mutates the support array in place
+  support[16 * m + i] = sy;
+  weights[i] = w;
+}
+
+__device__ __forceinline__ bool window2(const Ib2& G, long long ix, long long iy, int lane, long long& off) {
+  const long long x = ix + (lane & 3) - kW2 + 1, y = iy + (lane >> 2) - kW2 + 1;
+  off = y * G.px + x;
+  return x >= 0 && x < G.px && y >= 0 && y < G.py;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k2_ib_interp(double* __restrict__ lag, const T* __restrict__ eul,
+                                                    const double* __restrict__ weights,
+                                                    const long long* __restrict__ index, long long m, int ncomp,
+                                                    Ib2 G, double dx_pow) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long node = gid >> 4;
+  const int lane = (int)(gid & 15);
+  const bool live = node < m;  // every lane takes part in the shuffles
+  long long off = 0;
+  const bool ok = live && window2(G, index[node], index[m + node], lane, off);
+  const double w = live ? weights[(long long)lane * m + node] : 0.0;
+  for (int c = 0; c < ncomp; ++c) {
+    double v = ok ? (double)eul[c * G.n + off] * w : 0.0;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    if (live && lane == 0) lag[c * m + node] = v * dx_pow;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k2_ib_spread(T* __restrict__ eul, const double* __restrict__ lag,
+                                                    const double* __restrict__ weights,
+                                                    const long long* __restrict__ index, long long m, int ncomp,
+                                                    Ib2 G) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long node = gid >> 4;
+  if (node >= m) return;
+  const int lane = (int)(gid & 15);
+  long long off;
+  if (!window2(G, index[node], index[m + node], lane, off)) return;
+  const double w = weights[(long long)lane * m + node];
+  for (int c = 0; c < ncomp; ++c) atomicAdd(eul + c * G.n + off, (T)(lag[c * m + node] * w));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_clear_ghosts(T* __restrict__ f, G2 G, int ncomp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.n * ncomp) return;
+  const long long r = i % G.n;
+  const int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
+  if (x < G.g || x >= G.px - G.g || y < G.g || y >= G.py - G.g) f[i] = T(0);
+}
+
+}  // namespace
+
+extern "C" int smi2d_ib_support(smi_ctx* c, void* support, void* nearest_index, const void* lag_positions, int64_t m,
+                                double dx, double coord_shift) {
+  SMI_CHECK(require_2d(c, "smi2d_ib_support"));
+  SMI_REQUIRE(support && nearest_index && lag_positions && m >= 0, "smi2d_ib_support: bad argument");
+  if (m == 0) return 0;
+  k2_ib_support<<<nblocks(16 * m), 256, 0, c->stream>>>((double*)support, (long long*)nearest_index,
+                                                       (const double*)lag_positions, m, make_ib2(c, dx, coord_shift));
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_ib_weights(smi_ctx* c, void* weights, void* support, int64_t m, double dx, int kernel_type) {
+  SMI_CHECK(require_2d(c, "smi2d_ib_weights"));
+  SMI_REQUIRE(weights && support && m >= 0, "smi2d_ib_weights: bad argument");
+  SMI_REQUIRE(kernel_type == SMI_DELTA_COSINE || kernel_type == SMI_DELTA_PESKIN,
+              "Invalid interpolation kernel type. Currently supported types are 'cosine' and 'peskin'.");
+  if (m == 0) return 0;
+  k2_ib_weights<<<nblocks(16 * m), 256, 0, c->stream>>>((double*)weights, (double*)support, m, dx, kernel_type,
+                                                       make_delta2(c, dx));
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi2d_ib_interpolate(smi_ctx* c, void* lag_field, const void* eul_field, const void* weights,
+                                    const void* nearest_index, int64_t m, int ncomp, double dx) {
+  SMI_CHECK(require_2d(c, "smi2d_ib_interpolate"));
+  SMI_REQUIRE(lag_field && eul_field && weights && nearest_index && m >= 0 && ncomp >= 1,
+              "smi2d_ib_interpolate: bad argument");
+  SMI_REQUIRE(c->g >= kW2, "ghost size (%d) needs to be >= interp kernel width (%d)", c->g, kW2);
+  if (m == 0) return 0;
+  Ib2 G = make_ib2(c, dx, 0.0);
+  SMI_DISPATCH(c, {
+    k2_ib_interp<T><<<nblocks(16 * m), 256, 0, c->stream>>>((double*)lag_field, (const T*)eul_field,
+                                                          (const double*)weights, (const long long*)nearest_index, m,
+                                                          ncomp, G, dx * dx);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// Spreading followed by the single-rank ghost sum (every neighbour is PROC_NULL: ghosts are cleared)
+extern "C" int smi2d_ib_spread(smi_ctx* c, void* eul_field, const void* lag_field, const void* weights,
+                               const void* nearest_index, int64_t m, int ncomp, int ghost_sum) {
+  SMI_CHECK(require_2d(c, "smi2d_ib_spread"));
+  SMI_REQUIRE(eul_field && lag_field && weights && nearest_index && m >= 0 && ncomp >= 1,
+              "smi2d_ib_spread: bad argument");
+  SMI_REQUIRE(c->g >= kW2, "ghost size (%d) needs to be >= interp kernel width (%d)", c->g, kW2);
+  Ib2 G = make_ib2(c, 1.0, 0.0);
+  G2 P = geo2(c);
+  SMI_DISPATCH(c, {
+    if (m > 0)
+      k2_ib_spread<T><<<nblocks(16 * m), 256, 0, c->stream>>>((T*)eul_field, (const double*)lag_field,
+                                                            (const double*)weights, (const long long*)nearest_index,
+                                                            m, ncomp, G);
+    if (ghost_sum) k2_clear_ghosts<T><<<nblocks(P.n * ncomp), kB, 0, c->stream>>>((T*)eul_field, P, ncomp);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}

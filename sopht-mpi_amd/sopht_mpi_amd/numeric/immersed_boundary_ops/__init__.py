@@ -77,8 +77,67 @@ class EulerianLagrangianGridCommunicatorMPI3D:
         self.eulerian_grid_ghost_sum(local_field=eul_grid_field)
 
 
+class EulerianLagrangianGridCommunicatorMPI2D:
+    """EulerianLagrangianGridCommunicatorMPI2D.py:7-113 on one GPU: index (2, M) int64 (x, y), support
+    (2, 4, 4, M) float64, weights (4, 4, M) float64, Lagrangian fields (2, M) or (M,)."""
+
+    def __init__(self, dx, eul_grid_coord_shift, interp_kernel_width, real_t, mpi_construct, ghost_size,
+                 n_components=1, interp_kernel_type="cosine"):
+        if ghost_size < interp_kernel_width:
+            raise ValueError(
+                f"ghost size ({ghost_size}) needs to be >= interp kernel width ({interp_kernel_width})"
+            )
+        if interp_kernel_width != 2:
+            raise AssertionError("Interpolation kernel inconsistent with interpolation kernel width!")
+        if n_components not in (1, 2):
+            raise AssertionError("invalid number of components for interpolation!")
+        if interp_kernel_type not in _KERNEL_TYPES:
+            raise ValueError(
+                "Invalid interpolation kernel type. Currently supported types are 'cosine' and 'peskin'."
+            )
+        self.mpi_construct = mpi_construct
+        self.ctx = mpi_construct.device_context(ghost_size)
+        self.dx = float(dx)
+        self.coord_shift = float(eul_grid_coord_shift)
+        self.n_components = n_components
+        self.kernel_type = _KERNEL_TYPES[interp_kernel_type]
+        self.mpi_substart_idx = np.zeros(2, dtype=np.int64)
+        self.mpi_local_substart_coord_shift = self.mpi_substart_idx - ghost_size
+
+    def local_eulerian_grid_support_of_lagrangian_grid_kernel(self, local_eul_grid_support_of_lag_grid,
+                                                              nearest_eul_grid_index_to_lag_grid, lag_positions):
+        call("smi2d_ib_support", self.ctx.handle, as_ptr(local_eul_grid_support_of_lag_grid),
+             as_ptr(nearest_eul_grid_index_to_lag_grid), as_ptr(lag_positions), lag_positions.shape[-1], self.dx,
+             self.coord_shift)
+
+    def interpolation_weights_kernel(self, interp_weights, local_eul_grid_support_of_lag_grid):
+        call("smi2d_ib_weights", self.ctx.handle, as_ptr(interp_weights), as_ptr(local_eul_grid_support_of_lag_grid),
+             interp_weights.shape[-1], self.dx, self.kernel_type)
+
+    def eulerian_to_lagrangian_grid_interpolation_kernel(self, lag_grid_field, eul_grid_field, interp_weights,
+                                                         nearest_eul_grid_index_to_lag_grid):
+        call("smi2d_ib_interpolate", self.ctx.handle, as_ptr(lag_grid_field), as_ptr(eul_grid_field),
+             as_ptr(interp_weights), as_ptr(nearest_eul_grid_index_to_lag_grid), lag_grid_field.shape[-1],
+             self.n_components, self.dx)
+
+    def lagrangian_to_eulerian_grid_interpolation_kernel_without_ghost_sum(self, eul_grid_field, lag_grid_field,
+                                                                           interp_weights,
+                                                                           nearest_eul_grid_index_to_lag_grid):
+        call("smi2d_ib_spread", self.ctx.handle, as_ptr(eul_grid_field), as_ptr(lag_grid_field),
+             as_ptr(interp_weights), as_ptr(nearest_eul_grid_index_to_lag_grid), lag_grid_field.shape[-1],
+             self.n_components, 0)
+
+    def lagrangian_to_eulerian_grid_interpolation_kernel(self, eul_grid_field, lag_grid_field, interp_weights,
+                                                         nearest_eul_grid_index_to_lag_grid):
+        """:99-113: spread, then the ghost sum (one rank: the ghost cells are cleared)."""
+        call("smi2d_ib_spread", self.ctx.handle, as_ptr(eul_grid_field), as_ptr(lag_grid_field),
+             as_ptr(interp_weights), as_ptr(nearest_eul_grid_index_to_lag_grid), lag_grid_field.shape[-1],
+             self.n_components, 1)
+
+
 class VirtualBoundaryForcingMPI:
-    """VirtualBoundaryForcingMPI.py:21-459 (3D).
+    """VirtualBoundaryForcingMPI.py:21-459.  3D as described below; 2D (one GPU) runs the
+    communicator's four kernels one after the other and forms the penalty force on the host.
 
     Global Lagrangian arrays (``global_lag_grid_*``) are host numpy arrays owned by the master
     rank as in the reference; the ``local_lag_grid_*`` arrays of this slab's nodes live on the
@@ -92,9 +151,9 @@ class VirtualBoundaryForcingMPI:
                  global_lag_grid_position_field=None, assume_data_locality=False, interp_kernel_type="cosine"):
         if grid_dim != 2 and grid_dim != 3:
             raise ValueError("Invalid grid dimensions for virtual boundary forcing!")
-        if grid_dim != 3:
-            raise NotImplementedError("the GPU immersed-boundary path is 3D only")
         self.grid_dim = grid_dim
+        if grid_dim == 2:
+            assume_data_locality = True  # one rank owns every node
         self.virtual_boundary_stiffness_coeff = virtual_boundary_stiffness_coeff
         self.virtual_boundary_damping_coeff = virtual_boundary_damping_coeff
         self.time = start_time
@@ -113,7 +172,8 @@ class VirtualBoundaryForcingMPI:
         self.mpi_construct = mpi_construct
         self.master_rank = master_rank
         self.dx = float(dx)
-        self.eul_lag_grid_communicator = EulerianLagrangianGridCommunicatorMPI3D(
+        comm_cls = EulerianLagrangianGridCommunicatorMPI3D if grid_dim == 3 else EulerianLagrangianGridCommunicatorMPI2D
+        self.eul_lag_grid_communicator = comm_cls(
             dx=dx, eul_grid_coord_shift=eul_grid_coord_shift, interp_kernel_width=self.interp_kernel_width,
             real_t=self.eul_grid_real_t, n_components=grid_dim, mpi_construct=mpi_construct, ghost_size=ghost_size,
             interp_kernel_type=interp_kernel_type,
@@ -160,6 +220,11 @@ class VirtualBoundaryForcingMPI:
         self.local_lag_grid_forcing_field = z()
         self.local_lag_grid_position_field = z()
         self.local_lag_grid_velocity_field = z()
+        if self.grid_dim == 2:
+            win = (4, 4, num_lag_nodes)
+            self.local_eul_grid_support_of_lag_grid = self.ctx.zeros((2,) + win, np.float64)
+            self.nearest_eul_grid_index_to_lag_grid = self.ctx.zeros((2, num_lag_nodes), np.int64)
+            self.interp_weights = self.ctx.zeros(win, np.float64)
 
     def update_buffers(self, global_lag_grid_position_field):
         """:238-276: re-map nodes to slabs; re-scatter the mismatch state when ownership changed."""
@@ -208,6 +273,22 @@ class VirtualBoundaryForcingMPI:
             self.mpi_lagrangian_field_communicator._compute_lag_nodes_rank_address(global_lag_grid_position_field)
         self._upload_lagrangian_state(global_lag_grid_position_field, global_lag_grid_velocity_field)
         comm = self.eul_lag_grid_communicator
+        if self.grid_dim == 2:
+            # :360-397 step by step: support and index, weights, E -> L velocity, mismatch, penalty force
+            comm.local_eulerian_grid_support_of_lagrangian_grid_kernel(
+                self.local_eul_grid_support_of_lag_grid, self.nearest_eul_grid_index_to_lag_grid,
+                self.local_lag_grid_position_field)
+            comm.interpolation_weights_kernel(self.interp_weights, self.local_eul_grid_support_of_lag_grid)
+            comm.eulerian_to_lagrangian_grid_interpolation_kernel(
+                self.local_lag_grid_flow_velocity_field, local_eul_grid_velocity_field, self.interp_weights,
+                self.nearest_eul_grid_index_to_lag_grid)
+            vmis = self.local_lag_grid_flow_velocity_field.get() - np.asarray(global_lag_grid_velocity_field)
+            forcing = (self.virtual_boundary_stiffness_coeff * self.local_lag_grid_position_mismatch_field.get()
+                       + self.virtual_boundary_damping_coeff * vmis)
+            self.local_lag_grid_velocity_mismatch_field.set(vmis)
+            self.local_lag_grid_forcing_field.set(forcing)
+            self.global_lag_grid_forcing_field[...] = forcing
+            return
         call("smi_ib_forcing_fused", self.ctx.handle, as_ptr(self.local_lag_grid_forcing_field),
              as_ptr(self.local_lag_grid_velocity_mismatch_field), as_ptr(self.local_lag_grid_flow_velocity_field),
              as_ptr(self.local_lag_grid_position_mismatch_field), as_ptr(self.local_lag_grid_position_field),
@@ -230,6 +311,11 @@ class VirtualBoundaryForcingMPI:
             local_eul_grid_velocity_field, global_lag_grid_position_field, global_lag_grid_velocity_field
         )
         comm = self.eul_lag_grid_communicator
+        if self.grid_dim == 2:
+            comm.lagrangian_to_eulerian_grid_interpolation_kernel(
+                local_eul_grid_forcing_field, self.local_lag_grid_forcing_field, self.interp_weights,
+                self.nearest_eul_grid_index_to_lag_grid)
+            return
         call("smi_ib_spread_fused", self.ctx.handle, as_ptr(local_eul_grid_forcing_field),
              as_ptr(self.local_lag_grid_forcing_field), as_ptr(self.local_lag_grid_position_field),
              self.local_num_lag_nodes, comm.dx, comm.coord_shift, comm._substart, comm.kernel_type)
@@ -240,8 +326,8 @@ class VirtualBoundaryForcingMPI:
         global_lag_grid_velocity_field,
     ):
         """:431-450."""
-        call("smi_set_fixed_val", self.ctx.handle, as_ptr(local_eul_grid_forcing_field), self.grid_dim,
-             _lib.darray([0.0] * self.grid_dim))
+        call("smi_set_fixed_val" if self.grid_dim == 3 else "smi2d_set_fixed_val", self.ctx.handle,
+             as_ptr(local_eul_grid_forcing_field), self.grid_dim, _lib.darray([0.0] * self.grid_dim))
         self.compute_interaction_force_on_eul_and_lag_grid(
             local_eul_grid_forcing_field, local_eul_grid_velocity_field, global_lag_grid_position_field,
             global_lag_grid_velocity_field,
@@ -255,4 +341,5 @@ class VirtualBoundaryForcingMPI:
         self.time += dt
 
 
-__all__ = ["EulerianLagrangianGridCommunicatorMPI3D", "VirtualBoundaryForcingMPI"]
+__all__ = ["EulerianLagrangianGridCommunicatorMPI2D", "EulerianLagrangianGridCommunicatorMPI3D",
+           "VirtualBoundaryForcingMPI"]

@@ -142,3 +142,91 @@ def test_2d_invalid_arguments(smi):
                                  flow_type="passive_scalar", with_free_stream_flow=True)
     with pytest.raises(ValueError):
         UnboundedFlowSimulator2D(grid_size=(16, 16), x_range=1.0, kinematic_viscosity=1.0, ghost_size=1)
+
+
+@pytest.mark.parametrize("kernel_type", ["cosine", "peskin"])
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+def test_2d_immersed_boundary_operators(smi, real_t, kernel_type):
+    from oracle import immersed_boundary as oib
+    from sopht_mpi_amd.numeric.immersed_boundary_ops import EulerianLagrangianGridCommunicatorMPI2D
+    from sopht_mpi_amd.utils import MPIConstruct2D
+
+    rng = np.random.default_rng(31)
+    n, g, m = (24, 32), 2, 41
+    dx = real_t(1.0 / n[1])
+    shift = real_t(dx / 2)
+    construct = MPIConstruct2D(*n, real_t=real_t)
+    comm = EulerianLagrangianGridCommunicatorMPI2D(dx=dx, eul_grid_coord_shift=shift, interp_kernel_width=2,
+                                                   real_t=real_t, mpi_construct=construct, ghost_size=g,
+                                                   n_components=2, interp_kernel_type=kernel_type)
+    ctx = comm.ctx
+    pos = rng.uniform(0.15, 0.6, (2, m))
+    pos[:, 0] = (np.array([5, 6]) + 0.5) * float(dx)   # on a cell centre
+    pos[:, 1] = np.array([5, 6]) * float(dx)           # on cell faces
+    pshape = tuple(k + 2 * g for k in n)
+    dpos = ctx.from_numpy(pos)
+    dsup, didx = ctx.zeros((2, 4, 4, m), np.float64), ctx.zeros((2, m), np.int64)
+    dwts = ctx.zeros((4, 4, m), np.float64)
+    comm.local_eulerian_grid_support_of_lagrangian_grid_kernel(dsup, didx, dpos)
+    w_sup, w_idx = np.empty((2, 4, 4, m)), np.empty((2, m), dtype=np.int64)
+    oib.local_eulerian_grid_support_of_lagrangian_grid(w_sup, w_idx, pos, dx, shift, 2, np.zeros(2, dtype=np.int64) - g)
+    assert np.array_equal(didx.get(), w_idx), "nearest index must be bit exact"
+    assert_close(dsup.get(), w_sup, np.float64, scale=float(dx), factor=10, what="2D support")
+    comm.interpolation_weights_kernel(dwts, dsup)
+    w_wts = np.empty((4, 4, m))
+    (oib.cosine_interpolation_weights if kernel_type == "cosine" else oib.peskin_interpolation_weights)(
+        w_wts, w_sup, dx, real_t)
+    assert_close(dwts.get(), w_wts, np.float64, factor=100, what="2D weights")
+    const = ctx.from_numpy(np.full((2,) + pshape, 2.0, dtype=real_t))
+    dlag = ctx.zeros((2, m), np.float64)
+    comm.eulerian_to_lagrangian_grid_interpolation_kernel(dlag, const, dwts, didx)
+    np.testing.assert_allclose(dlag.get(), 2.0, rtol=1e-6 if real_t == np.float32 else 1e-12)
+    eul = rand_field(rng, (2,) + pshape, real_t)
+    comm.eulerian_to_lagrangian_grid_interpolation_kernel(dlag, ctx.from_numpy(eul), dwts, didx)
+    w_lag = np.zeros((2, m))
+    oib.eulerian_to_lagrangian_grid_interpolation(w_lag, eul, w_wts, w_idx, dx)
+    assert_close(dlag.get(), w_lag, np.float64, factor=1e4, what="2D E->L")
+    lag = rng.standard_normal((2, m))
+    dfor = ctx.from_numpy(eul)
+    comm.lagrangian_to_eulerian_grid_interpolation_kernel(dfor, ctx.from_numpy(lag), dwts, didx)
+    w_for = eul.copy()
+    oib.lagrangian_to_eulerian_grid_interpolation(w_for, lag, w_wts, w_idx)
+    oib.clear_ghost_cells(w_for, g, 2)
+    assert_close(dfor.get(), w_for, real_t, factor=4, what="2D L->E")
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+def test_2d_virtual_boundary_forcing(smi, real_t):
+    from oracle import immersed_boundary as oib
+    from sopht_mpi_amd.numeric.immersed_boundary_ops import VirtualBoundaryForcingMPI
+    from sopht_mpi_amd.utils import MPIConstruct2D
+
+    rng = np.random.default_rng(32)
+    n, g, m = (32, 32), 2, 120
+    dx = real_t(1.0 / n[1])
+    construct = MPIConstruct2D(*n, real_t=real_t)
+    theta = np.linspace(0, 2 * np.pi, m, endpoint=False)
+    pos = np.stack([0.5 + 0.2 * np.cos(theta), 0.45 + 0.15 * np.sin(theta)])
+    vel = rng.standard_normal((2, m)) * 0.1
+    k, c = -4.0e2, -2.0e1
+    gpu = VirtualBoundaryForcingMPI(mpi_construct=construct, ghost_size=g, virtual_boundary_stiffness_coeff=k,
+                                    virtual_boundary_damping_coeff=c, grid_dim=2, dx=dx,
+                                    global_lag_grid_position_field=pos)
+    cpu = oib.VirtualBoundaryForcing(k, c, 2, dx, m, g, eul_real_t=real_t)
+    ctx = gpu.ctx
+    pshape = tuple(q + 2 * g for q in n)
+    for step in range(3):
+        u = rand_field(rng, (2,) + pshape, real_t)
+        du, dforce = ctx.from_numpy(u), ctx.from_numpy(rand_field(rng, (2,) + pshape, real_t))
+        gpu.compute_interaction_forcing(local_eul_grid_forcing_field=dforce, local_eul_grid_velocity_field=du,
+                                        global_lag_grid_position_field=pos, global_lag_grid_velocity_field=vel)
+        w_force = np.zeros((2,) + pshape, dtype=real_t)
+        cpu.compute_interaction_force_on_eul_and_lag_grid(w_force, u, pos, vel)
+        assert_close(gpu.global_lag_grid_forcing_field, cpu.lag_forcing, np.float64, factor=1e5,
+                     what=f"2D lag forcing step {step}")
+        assert_close(dforce.get(), w_force, real_t, factor=8, what=f"2D eul forcing step {step}")
+        gpu.time_step(dt=1e-3)
+        cpu.time_step(1e-3)
+        pos = pos + 1e-3 * rng.standard_normal((2, m)) * 0.1
+    assert_close(gpu.local_lag_grid_position_mismatch_field.get(), cpu.lag_position_mismatch, np.float64,
+                 factor=1e5, what="2D position mismatch")
