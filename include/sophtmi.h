@@ -61,8 +61,9 @@ int smi_sync(smi_ctx* ctx);
  * MPI.COMM_WORLD.Create_cart (utils/mpi_utils_3d.py:64-66). */
 int smi_comm_unique_id(void* out128);
 int smi_comm_init(smi_ctx* ctx, const void* unique_id128);
-/* Host-side transport hook.  When set, every halo exchange (kind 0) and ghost sum
- * (kind 1) the library needs is handed to `cb` instead of RCCL; the callback moves whole
+/* Host-side transport hook.  When set, every halo exchange (kind 0: all ghost planes; kind 16 d:
+ * only the d planes next to the interior) and ghost sum (kind 1) the library needs is handed to
+ * `cb` instead of RCCL; the callback moves whole
  * ghost planes with smi_planes_d2h / smi_planes_h2d.  For ranks that share one GPU.
  * Replaces nothing in the reference (its transport is always MPI). */
 typedef int (*smi_exchange_cb)(void* user, void* field, int ncomp, int kind);

@@ -46,35 +46,48 @@ extern "C" int smi_allreduce_f64(smi_ctx* c, double* host_inout, int n, int op) 
 
 static inline ncclDataType_t nccl_type(const smi_ctx* c) { return c->dtype == SMI_F32 ? ncclFloat : ncclDouble; }
 
-// MPIGhostCommunicator3D z faces: my first / last g interior planes -> the neighbour's
-// high / low ghost planes.
-int smi_halo_exchange_impl(smi_ctx* c, void* field, int ncomp) {
+// MPIGhostCommunicator3D z faces: my first / last d interior planes -> the neighbour's
+// high / low ghost planes next to its interior.  d = g (what the reference exchanges) unless the
+// fused step has lowered halo_depth to what its stencils read.  Two fields may travel in one
+// group (one launch): the velocity and the vorticity ahead of the fused advection.
+int smi_halo_exchange2_impl(smi_ctx* c, void* field_a, int ncomp_a, void* field_b, int ncomp_b) {
   if (c->nranks == 1) return 0;
+  const int d = (c->halo_depth > 0 && c->halo_depth < c->g) ? c->halo_depth : c->g;
+  void* fields[2] = {field_a, field_b};
+  const int ncomps[2] = {ncomp_a, field_b ? ncomp_b : 0};
   if (c->exchange_cb) {
-    int rc = c->exchange_cb(c->exchange_user, field, ncomp, 0);
-    SMI_REQUIRE(rc == 0, "halo exchange callback failed (%d)", rc);
+    for (int f = 0; f < 2; ++f) {
+      if (!ncomps[f]) continue;
+      int rc = c->exchange_cb(c->exchange_user, fields[f], ncomps[f], d == c->g ? 0 : 16 * d);
+      SMI_REQUIRE(rc == 0, "halo exchange callback failed (%d)", rc);
+    }
     return 0;
   }
   SMI_REQUIRE(c->comm_ready, "halo exchange across ranks needs smi_comm_init or an exchange callback");
   const size_t es = smi_elem_size(c);
-  const size_t n = (size_t)c->g * c->plane;  // elements per face per component
-  char* base = (char*)field;
+  const size_t n = (size_t)d * c->plane;  // elements per face per component
   SMI_CHECK_NCCL(ncclGroupStart());
-  for (int k = 0; k < ncomp; ++k) {
-    char* f = base + (size_t)k * c->vol * es;
-    if (c->rank > 0) {
-      SMI_CHECK_NCCL(ncclSend(f + (size_t)c->g * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
-      SMI_CHECK_NCCL(ncclRecv(f, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+  for (int f = 0; f < 2; ++f)
+    for (int k = 0; k < ncomps[f]; ++k) {
+      char* p = (char*)fields[f] + (size_t)k * c->vol * es;
+      if (c->rank > 0) {
+        SMI_CHECK_NCCL(ncclSend(p + (size_t)c->g * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->g - d) * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm,
+                                c->stream));
+      }
+      if (c->rank < c->nranks - 1) {
+        SMI_CHECK_NCCL(ncclSend(p + (size_t)(c->pz - c->g - d) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
+                                c->stream));
+        SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
+                                c->stream));
+      }
     }
-    if (c->rank < c->nranks - 1) {
-      SMI_CHECK_NCCL(ncclSend(f + (size_t)(c->pz - 2 * c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
-                              c->stream));
-      SMI_CHECK_NCCL(ncclRecv(f + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
-                              c->stream));
-    }
-  }
   SMI_CHECK_NCCL(ncclGroupEnd());
   return 0;
+}
+
+int smi_halo_exchange_impl(smi_ctx* c, void* field, int ncomp) {
+  return smi_halo_exchange2_impl(c, field, ncomp, nullptr, 0);
 }
 
 // All-to-all of equal contiguous blocks: block r of `send` goes to rank r, block s of `recv`

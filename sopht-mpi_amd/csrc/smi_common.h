@@ -35,6 +35,7 @@ struct smi_ctx {
   smi_alltoall_cb alltoall_cb;
   SmiProf* prof;
   void* exchange_user;
+  int halo_depth;  // 0: exchange all g ghost planes; d < g: only the d planes next to the interior
 };
 
 constexpr int kRedBlocks = 2048;
@@ -107,6 +108,7 @@ __device__ __forceinline__ void store4(T* p, const Vec4<T>& v) {
 
 // internal cross-TU helpers
 int smi_halo_exchange_impl(smi_ctx* ctx, void* field, int ncomp);
+int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* field_b, int ncomp_b);
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);

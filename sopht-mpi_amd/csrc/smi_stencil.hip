@@ -938,8 +938,7 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
   SMI_REQUIRE(out != velocity && out != vorticity, "advection update: output and input must not alias");
   if (smi_multi_rank(c)) {
     // the ghost planes of u x w are the cross product of the exchanged ghost planes
-    SMI_CHECK(smi_halo_exchange_impl(c, velocity, 3));
-    SMI_CHECK(smi_halo_exchange_impl(c, vorticity, 3));
+    SMI_CHECK(smi_halo_exchange2_impl(c, velocity, 3, vorticity, 3));
   }
   Geo G = make_geo(c);
   SmiProfScope prof(c, PROF_FUSED_ADVECT, 9.0 * smi_S(c));

@@ -2,7 +2,30 @@
 // so that the host pays one call per step instead of one per operator.
 #include "smi_common.h"
 
+static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
+                          void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu, double dx,
+                          int penalty_width, const double* fac_lo, const double* fac_hi, const double* free_stream,
+                          int filter_order, int filter_type);
+
+// Every stencil of this step reads one ghost plane (kernel support 1) and every operator
+// refreshes the ghost planes of its own input, so only the plane next to the interior needs to
+// travel: half the halo bytes of the reference's full-depth exchange.  (The second ghost plane
+// then holds stale values; nothing inside the step reads them into interior cells.)
 extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
+                                  void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
+                                  double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
+                                  const double* free_stream, int filter_order, int filter_type) {
+  SMI_REQUIRE(c, "smi_flow_step_ns3d: null context");
+  const int saved = c->halo_depth;
+  const bool shallow = filter_order == 0 || (filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE);
+  if (shallow) c->halo_depth = 1;
+  const int rc = flow_step_body(c, p, vorticity, velocity, stream_func, buffer_vector, buffer_scalar, forcing, dt, nu,
+                                dx, penalty_width, fac_lo, fac_hi, free_stream, filter_order, filter_type);
+  c->halo_depth = saved;
+  return rc;
+}
+
+static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
                                   void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
                                   double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
                                   const double* free_stream, int filter_order, int filter_type) {

@@ -72,25 +72,28 @@ class DeviceContext:
 
         def exchange(_user, field, ncomp, kind):
             try:
-                n = ncomp * g * plane
                 send, recv = {}, {}
                 # kind 0 (halo): interior edge planes go out, ghost planes come in
+                # kind 16 d (halo of depth d < g): only the d planes next to the interior
                 # kind 1 (ghost sum): ghost planes go out, are ADDED to the neighbour's edge planes
-                src_lo, src_hi = (g, pz - 2 * g) if kind == 0 else (0, pz - g)
-                dst_lo, dst_hi = (0, pz - g) if kind == 0 else (g, pz - 2 * g)
+                d = kind // 16 if kind >= 16 else g
+                accumulate = 1 if kind == 1 else 0
+                n = ncomp * d * plane
+                src_lo, src_hi = (g, pz - g - d) if kind != 1 else (0, pz - g)
+                dst_lo, dst_hi = (g - d, pz - g) if kind != 1 else (g, pz - 2 * g)
                 if prev is not None:
                     send[prev] = np.empty(n, dtype=dt)
-                    call("smi_planes_d2h", self.handle, field, ncomp, src_lo, g, send[prev].ctypes.data)
+                    call("smi_planes_d2h", self.handle, field, ncomp, src_lo, d, send[prev].ctypes.data)
                     recv[prev] = np.empty(n, dtype=dt)
                 if nxt is not None:
                     send[nxt] = np.empty(n, dtype=dt)
-                    call("smi_planes_d2h", self.handle, field, ncomp, src_hi, g, send[nxt].ctypes.data)
+                    call("smi_planes_d2h", self.handle, field, ncomp, src_hi, d, send[nxt].ctypes.data)
                     recv[nxt] = np.empty(n, dtype=dt)
                 self.world.sendrecv(send, recv)
                 if prev is not None:
-                    call("smi_planes_h2d", self.handle, field, ncomp, dst_lo, g, recv[prev].ctypes.data, kind)
+                    call("smi_planes_h2d", self.handle, field, ncomp, dst_lo, d, recv[prev].ctypes.data, accumulate)
                 if nxt is not None:
-                    call("smi_planes_h2d", self.handle, field, ncomp, dst_hi, g, recv[nxt].ctypes.data, kind)
+                    call("smi_planes_h2d", self.handle, field, ncomp, dst_hi, d, recv[nxt].ctypes.data, accumulate)
                 return 0
             except Exception as exc:  # never let an exception cross the C boundary
                 import traceback
