@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--poisson", default=None, choices=[None, "rocfft", "pruned"])
     ap.add_argument("--cpu-grid", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -131,7 +132,7 @@ def main():
 
     world = get_world()
     rank = world.rank
-    n, real_t = args.grid, np.float32
+    n, real_t = args.grid, (np.float32 if args.dtype == "f32" else np.float64)
     sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=1e-3,
                                    flow_type="navier_stokes", real_t=real_t, ghost_size=2, penalty_zone_width=2,
                                    poisson_backend=args.poisson)
@@ -173,7 +174,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
             "workload": f"3D {n}^3 navier_stokes flow step (rotational advection + diffusion + penalise + "

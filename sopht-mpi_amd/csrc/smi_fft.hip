@@ -223,7 +223,9 @@ constexpr int tile_seqs(int L, int tps, bool f32, bool rows) {
   int want = rows ? 4 : (f32 ? SMI_FFT_COLS_F32 : 8);
   int ts = want;
   while (ts * L < 2048) ts *= 2;
-  while (ts > 1 && ts * tps > kMaxThreads) ts /= 2;
+  // double precision kernels hold twice the registers per lane: 512 lanes keep them out of scratch
+  const int max_threads = f32 ? kMaxThreads : kMaxThreads / 2;
+  while (ts > 1 && ts * tps > max_threads) ts /= 2;
   return ts;
 }
 
@@ -863,9 +865,9 @@ int smi_pruned_create(smi_poisson* p) {
   const size_t cs = 2 * smi_elem_size(c);
   const size_t nA = (size_t)G.P * G.nc * G.nzl * G.ny * G.KXP;
   const size_t nB = (size_t)G.nc * G.nz * 2 * G.ny * G.KXP;
-  // the kernels address one component slice with 32-bit element offsets scaled by the load
-  SMI_REQUIRE((nA / G.P / G.nc) * cs < (1ull << 32) && (size_t)G.nz * 2 * G.ny * G.KXP / 8 * cs < (1ull << 32) &&
-                  (size_t)(G.nz + 1) * G.KXP * smi_elem_size(c) < (1ull << 32),
+  // the column kernels index one workgroup's tile with 32-bit element offsets
+  SMI_REQUIRE((size_t)G.nz * 2 * G.ny * G.KXP / 8 < (1ull << 32) && (size_t)(2 * G.nz + 2) * G.KXP < (1ull << 32) &&
+                  (size_t)G.ny * G.KXP < (1ull << 32),
               "SMI_POISSON_PRUNED: grid too large for 32-bit tile offsets");
   SMI_CHECK_HIP(hipMalloc(&s->bufA, nA * cs));
   SMI_CHECK_HIP(hipMemsetAsync(s->bufA, 0, nA * cs, c->stream));

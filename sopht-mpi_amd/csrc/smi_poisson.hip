@@ -24,72 +24,76 @@
 
 namespace {
 constexpr int kBlock = 256;
+// capped grid: the kernels below stride over their range, so that ranges beyond 2^32 elements
+// (the doubled grid of a 1024^3 solve) stay within the launch limits
 inline int blocks_for(long long n) {
   long long b = (n + kBlock - 1) / kBlock;
-  return (int)b;
+  return (int)(b < (1 << 20) ? (b ? b : 1) : (1 << 20));
 }
+#define SMI_GRID_STRIDE(i, total)                                                   \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); \
+       i += (long long)gridDim.x * blockDim.x)
 
 // doubled[zz][yy][xx] = rhs interior or 0 (set_fixed_val + copy_to_doubled_domain, fused)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_pad_load(T* __restrict__ dbl, const T* __restrict__ rhs, int nz, int ny,
                                                      int nx, int g, int px, long long plane) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long n2x = 2LL * nx, n2y = 2LL * ny, total = 2LL * nz * n2y * n2x;
-  if (i >= total) return;
-  int xx = (int)(i % n2x);
-  long long r = i / n2x;
-  int yy = (int)(r % n2y), zz = (int)(r / n2y);
-  T v = T(0);
-  if (xx < nx && yy < ny && zz < nz) v = rhs[(long long)(zz + g) * plane + (long long)(yy + g) * px + (xx + g)];
-  dbl[i] = v;
+  const long long n2x = 2LL * nx, n2y = 2LL * ny, total = 2LL * nz * n2y * n2x;
+  SMI_GRID_STRIDE(i, total) {
+    int xx = (int)(i % n2x);
+    long long r = i / n2x;
+    int yy = (int)(r % n2y), zz = (int)(r / n2y);
+    T v = T(0);
+    if (xx < nx && yy < ny && zz < nz) v = rhs[(long long)(zz + g) * plane + (long long)(yy + g) * px + (xx + g)];
+    dbl[i] = v;
+  }
 }
 
 // Green's function on the doubled node grid (UnboundedPoissonSolverMPI3D.py:82-114)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_greens(T* __restrict__ dbl, int n2z, int n2y, int n2x, T dx, T two_xr,
                                                    T two_yr, T two_zr) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = (long long)n2z * n2y * n2x;
-  if (i >= total) return;
-  int xx = (int)(i % n2x);
-  long long r = i / n2x;
-  int yy = (int)(r % n2y), zz = (int)(r / n2y);
-  T x = (T)((double)xx * (double)dx), y = (T)((double)yy * (double)dx), z = (T)((double)zz * (double)dx);
-  T xr = fmin(x, two_xr - x), yr = fmin(y, two_yr - y), zr = fmin(z, two_zr - z);
-  T dist = sqrt(xr * xr + yr * yr + zr * zr);
-  T v = (T(1) / dist) / (T)(4 * M_PI);
-  if (i == 0) v = T(1) / ((T)(4 * M_PI) * dx);
-  dbl[i] = v;
+  const long long total = (long long)n2z * n2y * n2x;
+  SMI_GRID_STRIDE(i, total) {
+    int xx = (int)(i % n2x);
+    long long r = i / n2x;
+    int yy = (int)(r % n2y), zz = (int)(r / n2y);
+    T x = (T)((double)xx * (double)dx), y = (T)((double)yy * (double)dx), z = (T)((double)zz * (double)dx);
+    T xr = fmin(x, two_xr - x), yr = fmin(y, two_yr - y), zr = fmin(z, two_zr - z);
+    T dist = sqrt(xr * xr + yr * yr + zr * zr);
+    T v = (T(1) / dist) / (T)(4 * M_PI);
+    if (i == 0) v = T(1) / ((T)(4 * M_PI) * dx);
+    dbl[i] = v;
+  }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_scale(T* __restrict__ a, long long n, T s) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] *= s;
+  SMI_GRID_STRIDE(i, n) a[i] *= s;
 }
 
 // complex multiply in place: a *= b   (elementwise_complex_product)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_cmul(T* __restrict__ a, const T* __restrict__ b, long long ncplx) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ncplx) return;
-  T ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
-  a[2 * i] = ar * br - ai * bi;
-  a[2 * i + 1] = ar * bi + ai * br;
+  SMI_GRID_STRIDE(i, ncplx) {
+    T ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+    a[2 * i] = ar * br - ai * bi;
+    a[2 * i + 1] = ar * bi + ai * br;
+  }
 }
 
 // solution interior = doubled[first octant] * norm  (backward normalisation + copy_from_doubled_domain)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_extract(T* __restrict__ sol, const T* __restrict__ dbl, int nz, int ny,
                                                     int nx, int g, int px, long long plane, T norm) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = (long long)nz * ny * nx;
-  if (i >= total) return;
-  int x = (int)(i % nx);
-  long long r = i / nx;
-  int y = (int)(r % ny), z = (int)(r / ny);
-  T v = dbl[((long long)z * 2 * ny + y) * 2 * nx + x] * norm;
-  sol[(long long)(z + g) * plane + (long long)(y + g) * px + (x + g)] = v;
+  const long long total = (long long)nz * ny * nx;
+  SMI_GRID_STRIDE(i, total) {
+    int x = (int)(i % nx);
+    long long r = i / nx;
+    int y = (int)(r % ny), z = (int)(r / ny);
+    T v = dbl[((long long)z * 2 * ny + y) * 2 * nx + x] * norm;
+    sol[(long long)(z + g) * plane + (long long)(y + g) * px + (x + g)] = v;
+  }
 }
 }  // namespace
 

@@ -35,7 +35,9 @@ def _solver(smi, ctx, shape, x_range, real_t, backend):
                                      ((8, 12, 16), 2),
                                      # transform lengths 192, 384, 768 (radix 8 x R x 8 plans) on each axis
                                      ((8, 192, 384), 2), ((384, 8, 768), 2), ((8, 384, 16), 2), ((192, 8, 16), 2),
-                                     ((768, 8, 16), 2), ((8, 768, 16), 2), ((8, 8, 1536), 2)])
+                                     ((768, 8, 16), 2), ((8, 768, 16), 2), ((8, 8, 1536), 2),
+                                     # the longest power-of-two plans
+                                     ((1024, 8, 16), 2), ((8, 2048, 16), 2), ((8, 8, 4096), 2)])
 def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
     rng = np.random.default_rng(7)
     ctx = make_ctx(smi, shape, g, real_t)
