@@ -93,8 +93,10 @@ struct Plan {
   static constexpr int RM = POW2 ? 0 : L / 64;  // middle radix of the 8 x R x 8 plans
   static_assert(POW2 || (L % 64 == 0 && (RM == 3 || RM == 6 || RM == 12)), "unsupported transform length");
   static constexpr int N8 = POW2 ? LG / 3 : 0, REM = POW2 ? LG % 3 : 0, NST = POW2 ? N8 + (REM ? 1 : 0) : 3;
-  // threads per sequence: one per work item of 8 points, and 64 for the middle stage of a mixed plan
-  static constexpr int TPS = POW2 ? L8 : (L8 > 64 ? L8 : 64);
+  // threads per sequence: one per work item of 8 points; the 64 items of the middle stage of a
+  // mixed plan need 64 lanes, or 32 that take MI = 2 items each when those are three points wide
+  static constexpr int TPS = POW2 ? L8 : (L8 > 64 ? L8 : (RM == 3 ? 32 : 64));
+  static constexpr int MI = POW2 ? 1 : (TPS < 64 ? 64 / TPS : 1);
   static constexpr int radix(int s) { return s < N8 ? 8 : (1 << REM); }
   static constexpr int ns(int s) {  // product of the radices before stage s
     int n = 1;
@@ -214,13 +216,19 @@ __device__ __forceinline__ void butterflies(Cx<T> (&v)[8], const Twiddles<T, LG>
 constexpr int kThreads = 256;      // pointwise helper kernels
 constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per thread
 
+#ifndef SMI_FFT_ZCOLS_MIXED
+#define SMI_FFT_ZCOLS_MIXED 0
+#endif
+#ifndef SMI_FFT_Z_LEAN
+#define SMI_FFT_Z_LEAN 1
+#endif
 #ifndef SMI_FFT_COLS_F32
 #define SMI_FFT_COLS_F32 16
 #endif
 // Sequences per tile.  Column passes want >= 16 (f32) / 8 (f64) so that every row of the tile
 // is a whole 128-byte line; TS * L / 8 threads, at most 1024.
-constexpr int tile_seqs(int L, int tps, bool f32, bool rows) {
-  int want = rows ? 4 : (f32 ? SMI_FFT_COLS_F32 : 8);
+constexpr int tile_seqs(int L, int tps, bool f32, bool rows, int want_cols = 0) {
+  int want = rows ? 4 : (want_cols ? want_cols : (f32 ? SMI_FFT_COLS_F32 : 8));
   int ts = want;
   while (ts * L < 2048) ts *= 2;
   // double precision kernels hold twice the registers per lane: 512 lanes keep them out of scratch
@@ -352,7 +360,8 @@ __device__ __forceinline__ void dft_mid(Cx<T> (&x)[12]) {
 template <int SIGN, int LG, typename LAY, typename T, bool PP>
 __device__ __forceinline__ void fft_run_mixed(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u,
                                               const Twiddles<T, LG>& tw) {
-  constexpr int L8 = Plan<LG>::L8, R = Plan<LG>::RM;
+  constexpr int L8 = Plan<LG>::L8, R = Plan<LG>::RM, MI = Plan<LG>::MI, TPS = Plan<LG>::TPS;
+  static_assert(MI * R <= 12, "middle-stage items of a lane must fit x[]");
   const bool a8 = u < L8, am = u < 64;
   if (a8) dft8<SIGN>(v);
   Cx<T>* w = sel.next();
@@ -365,18 +374,27 @@ __device__ __forceinline__ void fft_run_mixed(Cx<T> (&v)[8], TileSel<T, PP>& sel
   if (am) {
     const Cx<T>* r = sel.cur;
 #pragma unroll
-    for (int q = 0; q < R; ++q) x[q] = r[LAY::idx(u + 64 * q, t)];
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int q = 0; q < R; ++q) x[i * R + q] = r[LAY::idx(u + i * TPS + 64 * q, t)];
   }
   sel.after_read();
   w = sel.next();
   if (am) {
     // table values rather than running powers: eleven chained products would cost accuracy
-#pragma unroll
-    for (int q = 1; q < R; ++q) x[q] = x[q] * sgn<SIGN>(tw.mid[q * tw.mid_step]);
-    dft_mid<SIGN, R>(x);
+    // (items u and u + TPS share u mod 8, hence their twiddles)
     const int k = u & 7;
 #pragma unroll
-    for (int q = 0; q < R; ++q) w[LAY::idx((u - k) * R + k + 8 * q, t)] = x[q];
+    for (int i = 0; i < MI; ++i) {
+      Cx<T> y[12];
+      y[0] = x[i * R];
+#pragma unroll
+      for (int q = 1; q < R; ++q) y[q] = x[i * R + q] * sgn<SIGN>(tw.mid[q * tw.mid_step]);
+      dft_mid<SIGN, R>(y);
+      const int j = u + i * TPS;
+#pragma unroll
+      for (int q = 0; q < R; ++q) w[LAY::idx((j - k) * R + k + 8 * q, t)] = y[q];
+    }
   }
   __syncthreads();
   if (a8) {
@@ -440,7 +458,26 @@ constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 struct PGeo {
   int nz, ny, nx, nzl, P, nc, KXL, KXP, zb_shift;
   int c0;  // first component of this launch (components c0 .. c0 + nc - 1)
+  int nct, n2, n3;  // column kernels: tiles per row, second and third extent of the launch
 };
+
+// The column kernels run on a one-dimensional grid whose blocks are dealt to the eight XCDs
+// round-robin by linear id.  A tile of TS columns narrower than a 128-byte line shares every
+// line with its PF - 1 neighbours; those get consecutive slots on the SAME XCD, so that its L2
+// fetches and writes back each line once.  Returns false for the blocks that pad the grid.
+template <int PF>
+__device__ __forceinline__ bool col_tile(const PGeo& G, int& ct, int& j, int& k) {
+  unsigned q = blockIdx.x;
+  if constexpr (PF > 1) {
+    const unsigned xcd = q & 7, slot = q >> 3;
+    q = ((slot / PF) * 8 + xcd) * PF + slot % PF;
+  }
+  ct = (int)(q % (unsigned)G.nct);
+  const unsigned r = q / (unsigned)G.nct;
+  j = (int)(r % (unsigned)G.n2);
+  k = (int)(r / (unsigned)G.n2);
+  return k < G.n3;
+}
 
 // element offset of bufB row (c, z, ky')
 __device__ __forceinline__ size_t rowB(const PGeo& G, int c, int z, int kyp) {
@@ -449,20 +486,28 @@ __device__ __forceinline__ size_t rowB(const PGeo& G, int c, int z, int kyp) {
          (size_t)G.KXP;
 }
 
-template <typename T, int LG, bool ROWS>
+template <typename T, int LG, bool ROWS, int WANT_COLS = 0>
 struct TileCfg {
   static constexpr int L = Plan<LG>::L, L8 = Plan<LG>::L8;
   static constexpr int TPS = Plan<LG>::TPS;
-  static constexpr int TS = tile_seqs(L, TPS, sizeof(T) == 4, ROWS), NT = TS * TPS;
+  static constexpr int TS = tile_seqs(L, TPS, sizeof(T) == 4, ROWS, WANT_COLS), NT = TS * TPS;
   static constexpr int PITCH = L + L / 8 + 1;                            // row layout
+  // waves per SIMD the register allocation must allow: single precision column kernels of 512
+  // lanes keep to 128 registers, like those of 1024, so that two of them fit a CU
+  static constexpr int WPE = sizeof(T) == 4 && !ROWS && TS * Plan<LG>::TPS >= 512 && Plan<LG>::POW2 ? 4 : 1;
   static constexpr int ELEMS = ROWS ? TS * PITCH : L * TS;               // one tile
   static constexpr bool PP = 2 * ELEMS * sizeof(Cx<T>) <= kLdsBudget;    // room for two tiles
   static constexpr size_t BYTES = (PP ? 2 : 1) * ELEMS * sizeof(Cx<T>);
   using Lay = typename std::conditional<ROWS, RowLayout<PITCH>, ColLayout<TS>>::type;
+  // column tiles per 128-byte line
+  static constexpr int PF = (!ROWS && TS * sizeof(Cx<T>) < 128) ? 128 / (TS * (int)sizeof(Cx<T>)) : 1;
 };
 
-#define FFT_KERNEL_PROLOGUE(ROWS)                                                      \
-  using Cfg = TileCfg<T, LG, ROWS>;                                                    \
+#define FFT_KERNEL_PROLOGUE(ROWS)          \
+  using DefaultCfg_ = TileCfg<T, LG, ROWS>; \
+  FFT_KERNEL_PROLOGUE_T(ROWS, DefaultCfg_)
+#define FFT_KERNEL_PROLOGUE_T(ROWS, CFG)                                               \
+  using Cfg = CFG;                                                                     \
   using Lay = typename Cfg::Lay;                                                       \
   constexpr int L = Cfg::L, L8 = Cfg::L8, TS = Cfg::TS;                                \
   extern __shared__ char smem[];                                                       \
@@ -484,12 +529,20 @@ struct TileCfg {
 // are transformed along with the rest (finite garbage that nothing reads) and no lane is
 // predicated off.
 
+// The z convolution holds three register sets (transform, even-parity result, prefetched next
+// column).  The mixed plans add the middle-stage operands on top, which does not fit 128
+// registers: their tiles are 8 columns wide, hence at most 512 lanes and 256 registers.
+template <typename T, int LG>
+using ZCfg = TileCfg<T, LG, false, SMI_FFT_ZCOLS_MIXED>;
+
 // ------------------------------------------------------------------------- y forward
 template <typename T, int LG>
-__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
+__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, false>::WPE))
     k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
-  const int c = G.c0 + blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
+  int ct, z, k;
+  if (!col_tile<Cfg::PF>(G, ct, z, k)) return;
+  const int c = G.c0 + k, col = ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const Cx<T>* src = in + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
   Cx<T>* dst = out + rowB(G, c, z, 0);
@@ -513,10 +566,12 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
 
 // ------------------------------------------------------------------------- y inverse
 template <typename T, int LG>
-__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
+__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, false>::WPE))
     k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
-  const int c = G.c0 + blockIdx.z, z = blockIdx.y, col = blockIdx.x * TS + t;
+  int ct, z, k;
+  if (!col_tile<Cfg::PF>(G, ct, z, k)) return;
+  const int c = G.c0 + k, col = ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const Cx<T>* src = in + rowB(G, c, z, 0);
   Cx<T>* dst = out + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
@@ -552,10 +607,17 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
 // column is requested as soon as the registers of the current one are free (after the odd
 // parity pre-twiddle), so its latency hides behind the second half of the arithmetic.
 template <typename T, int LG>
-__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
+__global__ void __launch_bounds__((ZCfg<T, LG>::NT), (ZCfg<T, LG>::WPE))
     k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
-  FFT_KERNEL_PROLOGUE(false)
-  const int kyc = blockIdx.y, col = blockIdx.x * TS + t;
+  using ZC_ = ZCfg<T, LG>;
+  FFT_KERNEL_PROLOGUE_T(false, ZC_)
+  // Plans beyond 512 points and the mixed ones do not fit the register file with the Green's
+  // values of both parities held across tiles and the next column requested two transforms
+  // ahead: they reload the former per tile and request the latter one transform ahead.
+  constexpr bool LEAN = SMI_FFT_Z_LEAN && !(Plan<LG>::POW2 && LG <= 9);
+  int ct, kyc, k;
+  if (!col_tile<Cfg::PF>(G, ct, kyc, k)) return;
+  const int col = ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const int ZB = 1 << G.zb_shift;
   const size_t blk = (size_t)(2 * G.ny) * ZB * G.KXP;  // elements per z block of one component
@@ -582,15 +644,17 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
     for (int pz = 0; pz < 2; ++pz) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * mul_c16(wu, m) : a0[m];
-      if (pz == 1 && it + 1 < ntile) {
+      if (!LEAN && pz == 1 && it + 1 < ntile) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) a0[m] = ok ? (next + m * mstep)[off] : Cx<T>{0, 0};
       }
       // Green's table values for the spectrum at kz = 2 z + pz: all eight loads are issued
       // before the transform so that their latency hides behind it
       T gval[8];
-      const unsigned goff_lo = (unsigned)(2 * u + pz) * G.KXP + col;                 // rows kz
-      const unsigned goff_hi = (unsigned)(2 * (L8 - 1 - u) + 1 - pz) * G.KXP + col;  // rows 2 nz - kz
+      unsigned gvar = 0;
+      if (LEAN) asm volatile("" : "+v"(gvar));  // reloaded per tile instead of held in registers
+      const unsigned goff_lo = (unsigned)(2 * u + pz) * G.KXP + col + gvar;                 // rows kz
+      const unsigned goff_hi = (unsigned)(2 * (L8 - 1 - u) + 1 - pz) * G.KXP + col + gvar;  // rows 2 nz - kz
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         // m < 4: row 2 m L/8 + (2u + pz).  m >= 4: row 2 nz - 2 m L/8 - (2u + pz), split as
@@ -604,6 +668,10 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT))
       // of the inverse wants from this work item: scale in registers and go straight on
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = scale(v[m], gval[m]);
+      if (LEAN && pz == 1 && it + 1 < ntile) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a0[m] = ok ? (next + m * mstep)[off] : Cx<T>{0, 0};
+      }
       fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
       if (pz == 0) {
 #pragma unroll
@@ -917,24 +985,35 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
   PGeo G = s->G;
   G.nc = nc;
   G.c0 = c0;
-  using Cfg = TileCfg<T, LG, false>;
-  constexpr int TS = Cfg::TS, NT = Cfg::NT;
-  const size_t lds_bytes = Cfg::BYTES;
-  // z_conv: one workgroup per (column tile, folded ky), looping over mirror rows and components
-  dim3 grid((G.KXL + TS - 1) / TS, which == 1 ? G.ny + 1 : G.nz, which == 1 ? 1 : nc);
-  const Cx<T>* tw = (const Cx<T>*)s->tw[which == 1 ? 2 : 1];
-  if (which == 0) {
-    SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG>, lds_bytes));
-    SmiProfScope prof(c, PROF_FFT_Y_FWD, 6.0 * nc * smi_S(c));
-    k_fft_y_fwd<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, tw);
-  } else if (which == 1) {
-    SMI_CHECK(set_lds((const void*)k_fft_z_conv<T, LG>, lds_bytes));
+  // one-dimensional grid over (column tile, z or folded ky, component), padded to whole XCD rounds
+  auto grid_for = [&](int ts, int pf, int n2, int n3) {
+    G.nct = (G.KXL + ts - 1) / ts;
+    G.n2 = n2;
+    G.n3 = n3;
+    const long long tiles = (long long)G.nct * n2 * n3, round = 8 * pf;
+    return dim3((unsigned)((tiles + round - 1) / round * round));
+  };
+  if (which == 1) {
+    // one workgroup per (column tile, folded ky), looping over mirror rows and components
+    using Cfg = ZCfg<T, LG>;
+    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, G.ny + 1, 1);
+    SMI_CHECK(set_lds((const void*)k_fft_z_conv<T, LG>, Cfg::BYTES));
     SmiProfScope prof(c, PROF_FFT_Z_CONV, 9.0 * nc * smi_S(c));
-    k_fft_z_conv<T, LG><<<grid, NT, lds_bytes, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G, tw);
+    k_fft_z_conv<T, LG><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G,
+                                                                 (const Cx<T>*)s->tw[2]);
   } else {
-    SMI_CHECK(set_lds((const void*)k_fft_y_inv<T, LG>, lds_bytes));
-    SmiProfScope prof(c, PROF_FFT_Y_INV, 6.0 * nc * smi_S(c));
-    k_fft_y_inv<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, tw);
+    using Cfg = TileCfg<T, LG, false>;
+    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, G.nz, nc);
+    const Cx<T>* tw = (const Cx<T>*)s->tw[1];
+    if (which == 0) {
+      SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG>, Cfg::BYTES));
+      SmiProfScope prof(c, PROF_FFT_Y_FWD, 6.0 * nc * smi_S(c));
+      k_fft_y_fwd<T, LG><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, tw);
+    } else {
+      SMI_CHECK(set_lds((const void*)k_fft_y_inv<T, LG>, Cfg::BYTES));
+      SmiProfScope prof(c, PROF_FFT_Y_INV, 6.0 * nc * smi_S(c));
+      k_fft_y_inv<T, LG><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, tw);
+    }
   }
   SMI_LAUNCH_CHECK();
   return 0;

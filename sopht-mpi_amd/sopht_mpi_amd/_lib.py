@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsophtmi.so")
+# SOPHT_MPI_AMD_LIB names another build of the same library (used to compare kernel variants)
+LIB_PATH = os.environ.get("SOPHT_MPI_AMD_LIB") or os.path.join(_HERE, "lib", "libsophtmi.so")
 
 SMI_F32, SMI_F64 = 0, 1
 SMI_POISSON_ROCFFT, SMI_POISSON_PRUNED = 0, 1
