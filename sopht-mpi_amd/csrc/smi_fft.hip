@@ -47,6 +47,8 @@ template <typename T>
 __device__ __forceinline__ Cx<T> scale(Cx<T> a, T s) { return {a.x * s, a.y * s}; }
 template <typename T>
 __device__ __forceinline__ Cx<T> conj(Cx<T> a) { return {a.x, -a.y}; }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // multiply by SIGN * i  (SIGN = -1: forward transform, +1: inverse)
 template <int SIGN, typename T>
 __device__ __forceinline__ Cx<T> mul_si(Cx<T> a) {
@@ -68,18 +70,20 @@ __device__ __forceinline__ void dft8(Cx<T> (&v)[8]) {
   dft4<SIGN>(e0, e1, e2, e3);
   dft4<SIGN>(o0, o1, o2, o3);
   const T h = (T)0.70710678118654752440;
-  // w8^k, w8 = exp(SIGN * 2 pi i / 8)
-  Cx<T> t1 = o1 * Cx<T>{h, SIGN * h};
-  Cx<T> t2 = mul_si<SIGN>(o2);
-  Cx<T> t3 = o3 * Cx<T>{-h, SIGN * h};
+  // w8^k, w8 = exp(SIGN * 2 pi i / 8): o1 w8 = h p1, o3 w8^3 = h p3, folded into the final
+  // additions as fused multiply-adds (the products have two uses each, which the compiler's
+  // contraction leaves alone)
+  const Cx<T> p1 = SIGN < 0 ? Cx<T>{o1.x + o1.y, o1.y - o1.x} : Cx<T>{o1.x - o1.y, o1.y + o1.x};
+  const Cx<T> p3 = SIGN < 0 ? Cx<T>{o3.y - o3.x, -o3.x - o3.y} : Cx<T>{-o3.x - o3.y, o3.x - o3.y};
+  const Cx<T> t2 = mul_si<SIGN>(o2);
   v[0] = e0 + o0;
   v[4] = e0 - o0;
-  v[1] = e1 + t1;
-  v[5] = e1 - t1;
+  v[1] = Cx<T>{fma_(h, p1.x, e1.x), fma_(h, p1.y, e1.y)};
+  v[5] = Cx<T>{fma_(-h, p1.x, e1.x), fma_(-h, p1.y, e1.y)};
   v[2] = e2 + t2;
   v[6] = e2 - t2;
-  v[3] = e3 + t3;
-  v[7] = e3 - t3;
+  v[3] = Cx<T>{fma_(h, p3.x, e3.x), fma_(h, p3.y, e3.y)};
+  v[7] = Cx<T>{fma_(-h, p3.x, e3.x), fma_(-h, p3.y, e3.y)};
 }
 
 // Compile-time plan of an L point transform.  The template key LG is log2(L) for powers of
@@ -459,6 +463,7 @@ struct PGeo {
   int nz, ny, nx, nzl, P, nc, KXL, KXP, zb_shift;
   int c0;  // first component of this launch (components c0 .. c0 + nc - 1)
   int nct, n2, n3;  // column kernels: tiles per row, second and third extent of the launch
+  int zg;           // y kernels: consecutive planes one workgroup walks over
 };
 
 // The column kernels run on a one-dimensional grid whose blocks are dealt to the eight XCDs
@@ -536,30 +541,69 @@ template <typename T, int LG>
 using ZCfg = TileCfg<T, LG, false, SMI_FFT_ZCOLS_MIXED>;
 
 // ------------------------------------------------------------------------- y forward
+// The y kernels walk over G.zg consecutive planes and the G.nc components of one column tile
+// (three tiles per workgroup in the launches below) and request the next tile's column while
+// the current one is transformed: with a single workgroup per CU nothing else would cover
+// that latency.
+struct YWalk {
+  int z0, zg, nc, ntile;
+  __device__ __forceinline__ YWalk(const PGeo& G, int zgroup) {
+    z0 = zgroup * G.zg;
+    zg = min(G.zg, G.nz - z0);
+    nc = G.nc;
+    ntile = zg * nc;
+  }
+  __device__ __forceinline__ void tile(const PGeo& G, int it, int& c, int& z) const {
+    const int k = it / zg;
+    c = G.c0 + k;
+    z = z0 + (it - k * zg);
+  }
+};
+
 template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, false>::WPE))
     k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
-  int ct, z, k;
-  if (!col_tile<Cfg::PF>(G, ct, z, k)) return;
-  const int c = G.c0 + k, col = ct * TS + t;
+  int ct, zgroup, k3;
+  if (!col_tile<Cfg::PF>(G, ct, zgroup, k3)) return;
+  const YWalk W(G, zgroup);
+  const int col = ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
-  const Cx<T>* src = in + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
-  Cx<T>* dst = out + rowB(G, c, z, 0);
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
   const unsigned off_in = (unsigned)u * G.KXP + col, off_out = (unsigned)u * kystride + col;
+  auto src_of = [&](int it) {
+    int c, z;
+    W.tile(G, it, c, z);
+    return in + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
+  };
+  auto dst_of = [&](int it) {
+    int c, z;
+    W.tile(G, it, c, z);
+    return out + rowB(G, c, z, 0);
+  };
   Cx<T> v[8], a0[8];
   // the column is read once and kept in registers for both parities
+  {
+    const Cx<T>* src = src_of(0);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) a0[m] = ok ? (src + (size_t)(m * L8) * G.KXP)[off_in] : Cx<T>{0, 0};
+    for (int m = 0; m < 8; ++m) a0[m] = ok ? (src + (size_t)(m * L8) * G.KXP)[off_in] : Cx<T>{0, 0};
+  }
+  for (int it = 0; it < W.ntile; ++it) {
+    Cx<T>* dst = dst_of(it);
+    const Cx<T>* nsrc = src_of(it + 1 < W.ntile ? it + 1 : it);
 #pragma unroll
-  for (int parity = 0; parity < 2; ++parity) {
+    for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
-    fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
-    if (ok) {
+      for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
+      if (parity == 1 && it + 1 < W.ntile) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) (dst + (size_t)(parity * L + m * L8) * kystride)[off_out] = v[m];
+        for (int m = 0; m < 8; ++m) a0[m] = ok ? (nsrc + (size_t)(m * L8) * G.KXP)[off_in] : Cx<T>{0, 0};
+      }
+      fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
+      if (ok) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) (dst + (size_t)(parity * L + m * L8) * kystride)[off_out] = v[m];
+      }
     }
   }
 }
@@ -569,28 +613,57 @@ template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, false>::WPE))
     k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(false)
-  int ct, z, k;
-  if (!col_tile<Cfg::PF>(G, ct, z, k)) return;
-  const int c = G.c0 + k, col = ct * TS + t;
+  int ct, zgroup, k3;
+  if (!col_tile<Cfg::PF>(G, ct, zgroup, k3)) return;
+  const YWalk W(G, zgroup);
+  const int col = ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
-  const Cx<T>* src = in + rowB(G, c, z, 0);
-  Cx<T>* dst = out + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
   const unsigned off_in = (unsigned)u * kystride + col, off_out = (unsigned)u * G.KXP + col;
-  Cx<T> v[8], res[8];
+  auto src_of = [&](int it) {
+    int c, z;
+    W.tile(G, it, c, z);
+    return in + rowB(G, c, z, 0);
+  };
+  auto dst_of = [&](int it) {
+    int c, z;
+    W.tile(G, it, c, z);
+    return out + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
+  };
+  // x0 / x1: even / odd half of the spectrum of the tile about to be transformed; each is
+  // requested again for the next tile as soon as it has been copied out
+  Cx<T> v[8], res[8], x0[8], x1[8];
+  {
+    const Cx<T>* src = src_of(0);
 #pragma unroll
-  for (int parity = 0; parity < 2; ++parity) {
+    for (int m = 0; m < 8; ++m) x0[m] = ok ? (src + (size_t)(m * L8) * kystride)[off_in] : Cx<T>{0, 0};
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
-      v[m] = ok ? (src + (size_t)(parity * L + m * L8) * kystride)[off_in] : Cx<T>{0, 0};
+    for (int m = 0; m < 8; ++m) x1[m] = ok ? (src + (size_t)(L + m * L8) * kystride)[off_in] : Cx<T>{0, 0};
+  }
+  for (int it = 0; it < W.ntile; ++it) {
+    Cx<T>* dst = dst_of(it);
+    const bool more = it + 1 < W.ntile;
+    const Cx<T>* nsrc = src_of(more ? it + 1 : it);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = x0[m];
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) x0[m] = ok ? (nsrc + (size_t)(m * L8) * kystride)[off_in] : Cx<T>{0, 0};
+    }
     fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
-    if (parity == 0) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) res[m] = v[m];
-    } else if (ok) {
+    for (int m = 0; m < 8; ++m) {
+      res[m] = v[m];
+      v[m] = x1[m];
+    }
+    if (more) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m)
-        (dst + (size_t)(m * L8) * G.KXP)[off_out] = res[m] + conj(mul_c16(wu, m)) * v[m];
+      for (int m = 0; m < 8; ++m) x1[m] = ok ? (nsrc + (size_t)(L + m * L8) * kystride)[off_in] : Cx<T>{0, 0};
+    }
+    fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
+    if (ok) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) (dst + (size_t)(m * L8) * G.KXP)[off_out] = res[m] + conj(mul_c16(wu, m)) * v[m];
     }
   }
 }
@@ -1003,7 +1076,8 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
                                                                  (const Cx<T>*)s->tw[2]);
   } else {
     using Cfg = TileCfg<T, LG, false>;
-    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, G.nz, nc);
+    G.zg = nc >= 3 ? 1 : 3;  // three tiles per workgroup
+    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, (G.nz + G.zg - 1) / G.zg, 1);
     const Cx<T>* tw = (const Cx<T>*)s->tw[1];
     if (which == 0) {
       SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG>, Cfg::BYTES));

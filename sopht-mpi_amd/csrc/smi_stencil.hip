@@ -614,14 +614,226 @@ __global__ void __launch_bounds__(kTileThreads) k_advect_tiled(T* __restrict__ o
   for (int z = ze + 1; z < z1; ++z) copy_plane(z);
 }
 
+// Position of a lane in the branch-free tiled kernels: its own four cells and its share of the
+// halo around the tile, always as one aligned 16-byte vector (lanes 0 .. 2 txl - 1: the rows
+// below / above; the next 2 ty lanes: the vector that ends / starts just outside a row, which
+// the LDS pitch of 4 txl + 8 has room for).  Lanes without cells or without halo duty read
+// the start of the plane and write a spare LDS row (`rows` + 1 of rows + 2), so that the
+// plane loop has no divergent branch apart from the final store.
+struct TileLane {
+  int y, x0;
+  bool own;
+  long long q, hq;   // plane offsets of the own vector and of the halo vector
+  int own_off, h_off;  // LDS offsets within one component tile
+};
+__device__ __forceinline__ TileLane tile_lane(const Geo& G, const TileShape& S, const Blk& B) {
+  TileLane L;
+  const int tyi = B.x / S.ntx, txi = B.x - tyi * S.ntx;
+  const int tid = threadIdx.x;
+  const int ly = tid / S.txl, lx = tid - ly * S.txl;
+  const int ty0 = tyi * S.ty, tx0 = txi * S.txl * 4;
+  const int spare = S.rows * S.pitch + 4;
+  L.y = ty0 + ly;
+  L.x0 = tx0 + 4 * lx;
+  L.own = ly < S.ty && L.y < G.py && L.x0 < G.px;
+  L.q = L.own ? (long long)L.y * G.px + L.x0 : 0;
+  L.own_off = L.own ? (ly + 1) * S.pitch + 4 + 4 * lx : spare;
+  const int nrow = 2 * S.txl, ntask = nrow + 2 * S.ty;
+  int hy, hx, off;
+  if (tid < nrow) {
+    const int top = tid >= S.txl, hl = tid - top * S.txl;
+    hy = top ? ty0 + S.ty : ty0 - 1;
+    hx = tx0 + 4 * hl;
+    off = (top ? S.ty + 1 : 0) * S.pitch + 4 + 4 * hl;
+  } else {
+    const int k = tid - nrow, right = k >= S.ty, r = k - right * S.ty;
+    hy = ty0 + r;
+    hx = right ? tx0 + 4 * S.txl : tx0 - 4;
+    off = (r + 1) * S.pitch + (right ? 4 + 4 * S.txl : 0);
+  }
+  const bool h_on = tid < ntask && hy >= 0 && hy < G.py && hx >= 0 && hx < G.px;
+  L.hq = h_on ? (long long)hy * G.px + hx : 0;
+  L.h_off = h_on ? off : spare;
+  return L;
+}
+
+// ---------------------------------------------------------------- diffusion, LDS tiled
+// k_diffusion_flux on the 16-byte path with the tiling of k_advect_tiled: the plane a lane is
+// about to need sits in one of two LDS tiles (own cells and the halo), its z-1 / z+1 values in
+// registers.  HBM then sees each input cell once per tile instead of once per neighbouring
+// row's workgroup (those run behind other XCDs' L2s).  Grid z = component.
+// Software pipeline, two planes deep: the loads of plane z + 2 are issued at the top of step z
+// and first touched at the end of step z + 1, and they are older than the store of step z,
+// so no step waits for a load or a store it has just issued.
+template <typename T, bool ADD>
+__global__ void __launch_bounds__(kTileThreads) k_diffuse_tiled(T* __restrict__ out, const T* __restrict__ f, T c,
+                                                               Geo G, int zchunk, TileShape S) {
+  extern __shared__ char smi_tile_smem[];
+  T* lds = reinterpret_cast<T*>(smi_tile_smem);
+  const Blk B = xcd_block<true>();
+  const TileLane L = tile_lane(G, S, B);
+  out += (long long)B.z * G.vol;
+  f += (long long)B.z * G.vol;
+  const int comp = (S.rows + 2) * S.pitch;
+  bool core[4];
+  {
+    const bool yc = L.own && in_core(L.y, G.py, G.g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) core[e] = yc && in_core(L.x0 + e, G.px, G.g);
+  }
+  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
+  const bool run = zs <= ze;  // uniform over the workgroup
+  for (int z = z0; z < (run ? zs : z1); ++z) {
+    if (L.own) st<T, 4>(out + z * G.plane + L.q, ADD ? ld<T, 4>(f + z * G.plane + L.q) : zero_pack<T, 4>());
+  }
+  if (!run) return;
+  const T* fo = f + L.q;
+  const T* fh = f + L.hq;
+  // The planes rotate through four register sets (and the halo through two) by the argument
+  // order of step(), not by copies: a copy of a register with a load in flight would wait for it.
+  Pack<T, 4> pa = ld<T, 4>(fo + (zs - 1) * G.plane), pb = ld<T, 4>(fo + zs * G.plane);
+  Pack<T, 4> pc = ld<T, 4>(fo + (zs + 1) * G.plane), pd, ha = ld<T, 4>(fh + (zs + 1) * G.plane), hb;
+  st<T, 4>(lds + (zs & 1) * comp + L.own_off, pb);
+  st<T, 4>(lds + (zs & 1) * comp + L.h_off, ld<T, 4>(fh + zs * G.plane));
+  auto step = [&](int z, const Pack<T, 4>& prev, const Pack<T, 4>& cur, const Pack<T, 4>& nxt, Pack<T, 4>& nxt2,
+                  const Pack<T, 4>& h1, Pack<T, 4>& h2) {
+    const long long zn = (long long)min(z + 2, G.pz - 1) * G.plane;
+    nxt2 = ld<T, 4>(fo + zn);  // in flight across this step
+    h2 = ld<T, 4>(fh + zn);
+    __syncthreads();
+    const int buf = z & 1;
+    const T* tc = lds + buf * comp + L.own_off;
+    const Pack<T, 4> ym = ld<T, 4>(tc - S.pitch), yp = ld<T, 4>(tc + S.pitch);
+    const T xm = tc[-1], xp = tc[4];
+    Pack<T, 4> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const T left = e == 0 ? xm : cur.v[e - 1], right = e == 3 ? xp : cur.v[e + 1];
+      const T val = c * (right + left + yp.v[e] + ym.v[e] + nxt.v[e] + prev.v[e] - T(6) * cur.v[e]);
+      o.v[e] = core[e] ? val : T(0);
+      if (ADD) o.v[e] = cur.v[e] + o.v[e];
+    }
+    if (L.own) st<T, 4>(out + z * G.plane + L.q, o);
+    st<T, 4>(lds + (buf ^ 1) * comp + L.own_off, nxt);
+    st<T, 4>(lds + (buf ^ 1) * comp + L.h_off, h1);
+  };
+  for (int z = zs; z <= ze; z += 4) {
+    step(z, pa, pb, pc, pd, ha, hb);
+    if (z + 1 > ze) break;
+    step(z + 1, pb, pc, pd, pa, hb, ha);
+    if (z + 2 > ze) break;
+    step(z + 2, pc, pd, pa, pb, ha, hb);
+    if (z + 3 > ze) break;
+    step(z + 3, pd, pa, pb, pc, hb, ha);
+  }
+  for (int z = ze + 1; z < z1; ++z) {
+    if (L.own) st<T, 4>(out + z * G.plane + L.q, ADD ? ld<T, 4>(f + z * G.plane + L.q) : zero_pack<T, 4>());
+  }
+}
+
+// ---------------------------------------------------------------- curl, LDS tiled
+// k_curl MODE 0 on the 16-byte path, tiled and pipelined like k_diffuse_tiled: the three
+// components of the current plane are parked in LDS for the y+-1 / x+-1 reads, f_x and f_y of
+// the planes z-1 / z+1 stay in registers.
 template <typename T>
-static TileShape tile_shape(const smi_ctx* c) {
+__global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out, const T* __restrict__ f, T pref,
+                                                            Geo G, int zchunk, TileShape S) {
+  extern __shared__ char smi_tile_smem[];
+  T* lds = reinterpret_cast<T*>(smi_tile_smem);
+  const Blk B = xcd_block<true>();
+  const TileLane L = tile_lane(G, S, B);
+  const int comp = (S.rows + 2) * S.pitch;
+  bool core[4];
+  {
+    const bool yc = L.own && in_core(L.y, G.py, G.g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) core[e] = yc && in_core(L.x0 + e, G.px, G.g);
+  }
+  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
+  const bool run = zs <= ze;  // uniform over the workgroup
+  const Pack<T, 4> zero = zero_pack<T, 4>();
+  for (int z = z0; z < (run ? zs : z1); ++z) {
+    if (L.own) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) st<T, 4>(out + k * G.vol + z * G.plane + L.q, zero);
+    }
+  }
+  if (!run) return;
+  const T* fo = f + L.q;
+  const T* fh = f + L.hq;
+  auto park = [&](int buf, int off, const Vec3<T, 4>& v) {
+    T* t = lds + buf * 3 * comp + off;
+    st<T, 4>(t, v.x);
+    st<T, 4>(t + comp, v.y);
+    st<T, 4>(t + 2 * comp, v.z);
+  };
+  // register rotation by argument order, as in k_diffuse_tiled
+  Vec3<T, 4> pa = ld3<T, 4>(fo + (zs - 1) * G.plane, G.vol), pb = ld3<T, 4>(fo + zs * G.plane, G.vol);
+  Vec3<T, 4> pc = ld3<T, 4>(fo + (zs + 1) * G.plane, G.vol), pd;
+  Vec3<T, 4> ha = ld3<T, 4>(fh + (zs + 1) * G.plane, G.vol), hb;
+  park(zs & 1, L.own_off, pb);
+  park(zs & 1, L.h_off, ld3<T, 4>(fh + zs * G.plane, G.vol));
+  auto step = [&](int z, const Vec3<T, 4>& prev, const Vec3<T, 4>& cur, const Vec3<T, 4>& nxt, Vec3<T, 4>& nxt2,
+                  const Vec3<T, 4>& h1, Vec3<T, 4>& h2) {
+    const long long zn = (long long)min(z + 2, G.pz - 1) * G.plane;
+    nxt2 = ld3<T, 4>(fo + zn, G.vol);  // in flight across this step
+    h2 = ld3<T, 4>(fh + zn, G.vol);
+    __syncthreads();
+    const int buf = z & 1;
+    const T* tx = lds + buf * 3 * comp + L.own_off;
+    const T* ty = tx + comp;
+    const T* tz = tx + 2 * comp;
+    const Pack<T, 4> fx_ym = ld<T, 4>(tx - S.pitch), fx_yp = ld<T, 4>(tx + S.pitch);
+    const Pack<T, 4> fz_ym = ld<T, 4>(tz - S.pitch), fz_yp = ld<T, 4>(tz + S.pitch);
+    const T fy_xm = ty[-1], fy_xp = ty[4], fz_xm = tz[-1], fz_xp = tz[4];
+    Pack<T, 4> rx, ry, rz;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const T fyL = e == 0 ? fy_xm : cur.y.v[e - 1], fyR = e == 3 ? fy_xp : cur.y.v[e + 1];
+      const T fzL = e == 0 ? fz_xm : cur.z.v[e - 1], fzR = e == 3 ? fz_xp : cur.z.v[e + 1];
+      const T cx = pref * (fz_yp.v[e] - fz_ym.v[e] - nxt.y.v[e] + prev.y.v[e]);
+      const T cy = pref * (nxt.x.v[e] - prev.x.v[e] - fzR + fzL);
+      const T cz = pref * (fyR - fyL - fx_yp.v[e] + fx_ym.v[e]);
+      rx.v[e] = core[e] ? cx : T(0);
+      ry.v[e] = core[e] ? cy : T(0);
+      rz.v[e] = core[e] ? cz : T(0);
+    }
+    if (L.own) {
+      const long long zo = z * G.plane + L.q;
+      st<T, 4>(out + zo, rx);
+      st<T, 4>(out + G.vol + zo, ry);
+      st<T, 4>(out + 2 * G.vol + zo, rz);
+    }
+    park(buf ^ 1, L.own_off, nxt);
+    park(buf ^ 1, L.h_off, h1);
+  };
+  for (int z = zs; z <= ze; z += 4) {
+    step(z, pa, pb, pc, pd, ha, hb);
+    if (z + 1 > ze) break;
+    step(z + 1, pb, pc, pd, pa, hb, ha);
+    if (z + 2 > ze) break;
+    step(z + 2, pc, pd, pa, pb, ha, hb);
+    if (z + 3 > ze) break;
+    step(z + 3, pd, pa, pb, pc, hb, ha);
+  }
+  for (int z = ze + 1; z < z1; ++z) {
+    if (L.own) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) st<T, 4>(out + k * G.vol + z * G.plane + L.q, zero);
+    }
+  }
+}
+
+template <typename T>
+static TileShape tile_shape(const smi_ctx* c, int ty_cap = 8) {
   TileShape S;
   const int lanes = c->px / 4;
   S.ntx = (lanes + 31) / 32;
   S.txl = (lanes + S.ntx - 1) / S.ntx;
   S.ty = kTileThreads / S.txl;
-  if (S.ty > 8) S.ty = 8;  // four-wave workgroups: several fit on a CU and hide each other's barriers
+  if (S.ty > ty_cap) S.ty = ty_cap;  // four-wave workgroups: several fit on a CU and hide each other's barriers
   S.nty = (c->py + S.ty - 1) / S.ty;
   S.pitch = 4 * S.txl + 8;
   S.rows = S.ty + 2;
@@ -850,6 +1062,38 @@ bool vec_ok(const smi_ctx* c, const void* a, const void* b) {
 
 int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
+#ifndef SMI_TILE_ZCHUNK
+#define SMI_TILE_ZCHUNK 16
+#endif
+#ifndef SMI_TILE_ROWS
+#define SMI_TILE_ROWS 8
+#endif
+// launch geometry of the LDS-tiled stencil kernels (ncomp_lds component tiles, two buffers)
+struct TiledLaunch {
+  TileShape S;
+  dim3 grid;
+  int threads, zchunk;
+  size_t lds_bytes;
+};
+template <typename T>
+TiledLaunch tiled_launch(const smi_ctx* c, int ncomp_lds, int grid_z) {
+  TiledLaunch t;
+  t.S = tile_shape<T>(c, SMI_TILE_ROWS);
+  t.zchunk = c->pz < SMI_TILE_ZCHUNK ? c->pz : SMI_TILE_ZCHUNK;
+  t.grid = dim3(t.S.ntx * t.S.nty, (c->pz + t.zchunk - 1) / t.zchunk, grid_z);
+  t.threads = (t.S.txl * t.S.ty + 63) / 64 * 64;  // whole waves covering the tile and its halo duty
+  t.lds_bytes = (size_t)2 * ncomp_lds * (t.S.rows + 2) * t.S.pitch * sizeof(T);  // two spare rows per tile
+  return t;
+}
+template <typename F>
+int allow_lds(F fn, bool& done) {
+  if (!done) {
+    SMI_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    done = true;
+  }
+  return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ C ABI
@@ -861,8 +1105,11 @@ extern "C" int smi_diffusion_flux(smi_ctx* c, void* flux, const void* field, dou
   SmiProfScope prof(c, PROF_DIFFUSION_FLUX, 2.0 * ncomp * smi_S(c));
   SMI_DISPATCH(c, {
     if (vec_ok<T>(c, flux, field)) {
-      LaunchShape s = plan<4>(c, ncomp);
-      k_diffusion_flux<T, 4><<<s.grid, kBlock, 0, c->stream>>>((T*)flux, (const T*)field, (T)prefactor, G, s.zchunk);
+      const TiledLaunch t = tiled_launch<T>(c, 1, ncomp);
+      static bool attr = false;
+      SMI_CHECK(allow_lds(k_diffuse_tiled<T, false>, attr));
+      k_diffuse_tiled<T, false><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)flux, (const T*)field, (T)prefactor,
+                                                                              G, t.zchunk, t.S);
     } else {
       LaunchShape s = plan<1>(c, ncomp);
       k_diffusion_flux<T, 1><<<s.grid, kBlock, 0, c->stream>>>((T*)flux, (const T*)field, (T)prefactor, G, s.zchunk);
@@ -890,8 +1137,11 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
   SmiProfScope prof(c, PROF_FUSED_DIFFUSE, 2.0 * ncomp * smi_S(c));
   SMI_DISPATCH(c, {
     if (vec_ok<T>(c, out, in)) {
-      LaunchShape s = plan<4>(c, ncomp);
-      k_diffusion_flux<T, 4, true><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, (T)prefactor, G, s.zchunk);
+      const TiledLaunch t = tiled_launch<T>(c, 1, ncomp);
+      static bool attr = false;
+      SMI_CHECK(allow_lds(k_diffuse_tiled<T, true>, attr));
+      k_diffuse_tiled<T, true><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)in, (T)prefactor, G,
+                                                                             t.zchunk, t.S);
     } else {
       LaunchShape s = plan<1>(c, ncomp);
       k_diffusion_flux<T, 1, true><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, (T)prefactor, G, s.zchunk);
@@ -908,7 +1158,12 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const void
   Geo G = make_geo(c);
   SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
   SMI_DISPATCH(c, {
-    if (vec_ok<T>(c, out, f) && vec_ok<T>(c, out, base)) {
+    if (MODE == 0 && vec_ok<T>(c, out, f)) {
+      const TiledLaunch t = tiled_launch<T>(c, 3, 1);
+      static bool attr = false;
+      SMI_CHECK(allow_lds(k_curl_tiled<T>, attr));
+      k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S);
+    } else if (vec_ok<T>(c, out, f) && vec_ok<T>(c, out, base)) {
       LaunchShape s = plan<4>(c, 1);
       k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
                                                            (const T*)base);
