@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 ALG_BYTES_PER_POINT_STEP = 1692.0
 MIN_BYTES_PER_POINT_STEP = 660.0
 IMPL_BYTES_PER_POINT_STEP = 408.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_hbm_traffic_512cubed_v3.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_counters_512cubed_v4.json")
 
 
 def synthetic_vorticity(position_field, real_t, seed=0, nblobs=8, sigma=0.05):
@@ -66,7 +66,22 @@ def measured_traffic(slot, grid, n_gpus):
     if n_gpus != 1 or list(rec.get("grid", [])) != [grid] * 3:
         return None
     k = rec["kernels"].get(slot)
-    return k["hbm_bytes"] if k else None
+    return k.get("hbm_bytes") if k else None
+
+
+def measured_valu_floor_ms(slot, grid, n_gpus):
+    """Time the wave-level VALU instructions of one launch need at the chip's scalar-f32 issue
+    rate (packed math is compiled out), from the same committed counter passes; None when
+    they do not cover this configuration."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    if n_gpus != 1 or list(rec.get("grid", [])) != [grid] * 3:
+        return None
+    k = rec["kernels"].get(slot)
+    return k.get("valu_floor_ms") if k else None
 
 
 def roofline_from_profile(prof, grid, n_gpus):
@@ -78,9 +93,15 @@ def roofline_from_profile(prof, grid, n_gpus):
     name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = rec["ms"] / rec["launches"]
     achieved = rec["alg_bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(name, grid, n_gpus),
-            "avg_launch_ms": avg_ms, "alg_bytes_per_launch": rec["alg_bytes"] / rec["launches"]}
+    out = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(name, grid, n_gpus),
+           "avg_launch_ms": avg_ms, "alg_bytes_per_launch": rec["alg_bytes"] / rec["launches"]}
+    floor = measured_valu_floor_ms(name, grid, n_gpus)
+    if floor is not None:
+        # second ceiling of the same kernel: its VALU instruction stream at the measured issue rate
+        out["valu_issue_floor_ms"] = floor
+        out["valu_issue_frac"] = floor / avg_ms
+    return out
 
 
 def cpu_baseline(grid, steps):

@@ -220,8 +220,8 @@ __device__ __forceinline__ void butterflies(Cx<T> (&v)[8], const Twiddles<T, LG>
 constexpr int kThreads = 256;      // pointwise helper kernels
 constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per thread
 
-#ifndef SMI_FFT_ZCOLS_MIXED
-#define SMI_FFT_ZCOLS_MIXED 0
+#ifndef SMI_FFT_ZCOLS
+#define SMI_FFT_ZCOLS 0
 #endif
 #ifndef SMI_FFT_Z_LEAN
 #define SMI_FFT_Z_LEAN 1
@@ -538,7 +538,7 @@ struct TileCfg {
 // column).  The mixed plans add the middle-stage operands on top, which does not fit 128
 // registers: their tiles are 8 columns wide, hence at most 512 lanes and 256 registers.
 template <typename T, int LG>
-using ZCfg = TileCfg<T, LG, false, SMI_FFT_ZCOLS_MIXED>;
+using ZCfg = TileCfg<T, LG, false, SMI_FFT_ZCOLS>;
 
 // ------------------------------------------------------------------------- y forward
 // The y kernels walk over G.zg consecutive planes and the G.nc components of one column tile
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__((ZCfg<T, LG>::NT), (ZCfg<T, LG>::WPE))
   // Plans beyond 512 points and the mixed ones do not fit the register file with the Green's
   // values of both parities held across tiles and the next column requested two transforms
   // ahead: they reload the former per tile and request the latter one transform ahead.
-  constexpr bool LEAN = SMI_FFT_Z_LEAN && !(Plan<LG>::POW2 && LG <= 9);
+  constexpr bool LEAN = SMI_FFT_Z_LEAN && (SMI_FFT_Z_LEAN > 1 || !(Plan<LG>::POW2 && LG <= 9));
   int ct, kyc, k;
   if (!col_tile<Cfg::PF>(G, ct, kyc, k)) return;
   const int col = ct * TS + t;
