@@ -112,6 +112,5 @@ int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* fiel
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
-int smi_update_vorticity_into_impl(smi_ctx* c, void* out, const void* vorticity, void* forcing, double prefactor);
 // true when this context has neighbours to exchange with
 static inline bool smi_multi_rank(const smi_ctx* c) { return c->nranks > 1; }

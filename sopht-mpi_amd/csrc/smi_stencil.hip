@@ -198,11 +198,9 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
 //   B = { ext(z), face(y), core(x) }                the two y boxes
 //   C = { ext(z), ext(y), face(x) }                 the two x boxes
 // (no band zeroing: update_vorticity_from_velocity_forcing_mpi_3d.py has no PROC_NULL logic).
-// MODE 2: the same update written to another array: out = base + p * curl(f) on U, out = base
-//   elsewhere (every cell of out is written; out must not alias base or f).
+// MODE 0 on the 16-byte path is served by k_curl_tiled; this kernel remains its scalar-path form.
 template <typename T, int V, int MODE>
-__global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f, T pref, Geo G, int zchunk,
-                                                 const T* base) {
+__global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f, T pref, Geo G, int zchunk) {
   long long q;
   int y, x0;
   const Blk B = xcd_block<false>();
@@ -232,16 +230,13 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
     ze = min(z1 - 1, G.pz - 2);
   }
   const Pack<T, V> zero = zero_pack<T, V>();
-  // cells this lane does not compute: 0 (MODE 0), untouched (MODE 1), copied from base (MODE 2)
-  const T* bx = MODE == 2 ? base + q : ox;
-  const T* by = MODE == 2 ? base + G.vol + q : oy;
-  const T* bz = MODE == 2 ? base + 2 * G.vol + q : oz;
+  // cells this lane does not compute: 0 (MODE 0), untouched (MODE 1)
   auto outside = [&](int z) {
     if (MODE == 1) return;
     const long long zo = z * G.plane;
-    st<T, V>(ox + zo, MODE == 0 ? zero : ld<T, V>(bx + zo));
-    st<T, V>(oy + zo, MODE == 0 ? zero : ld<T, V>(by + zo));
-    st<T, V>(oz + zo, MODE == 0 ? zero : ld<T, V>(bz + zo));
+    st<T, V>(ox + zo, zero);
+    st<T, V>(oy + zo, zero);
+    st<T, V>(oz + zo, zero);
   };
   if (!any || zs > ze) {
     for (int z = z0; z < z1; ++z) outside(z);
@@ -281,8 +276,8 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
       st<T, V>(ox + zo, rx);
       st<T, V>(oy + zo, ry);
       st<T, V>(oz + zo, rz);
-    } else if (anym || MODE == 2) {
-      Pack<T, V> wx = ld<T, V>(bx + zo), wy = ld<T, V>(by + zo), wz = ld<T, V>(bz + zo);
+    } else if (anym) {
+      Pack<T, V> wx = ld<T, V>(ox + zo), wy = ld<T, V>(oy + zo), wz = ld<T, V>(oz + zo);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         wx.v[e] = m[e] ? wx.v[e] + rx.v[e] : wx.v[e];
@@ -1152,8 +1147,8 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
 }
 
 template <int MODE>
-static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const void* base = nullptr) {
-  SMI_REQUIRE(out != f && out != base, "curl operators: output and input must not alias");
+static int run_curl(smi_ctx* c, void* out, void* f, double prefactor) {
+  SMI_REQUIRE(out != f, "curl operators: output and input must not alias");
   if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
   Geo G = make_geo(c);
   SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
@@ -1163,14 +1158,12 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const void
       static bool attr = false;
       SMI_CHECK(allow_lds(k_curl_tiled<T>, attr));
       k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S);
-    } else if (vec_ok<T>(c, out, f) && vec_ok<T>(c, out, base)) {
+    } else if (vec_ok<T>(c, out, f)) {
       LaunchShape s = plan<4>(c, 1);
-      k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
-                                                           (const T*)base);
+      k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
     } else {
       LaunchShape s = plan<1>(c, 1);
-      k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
-                                                           (const T*)base);
+      k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
     }
   });
   SMI_LAUNCH_CHECK();
@@ -1181,11 +1174,6 @@ extern "C" int smi_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vort
                                                           double prefactor) {
   SMI_REQUIRE(c && vorticity && forcing, "smi_update_vorticity_from_velocity_forcing: bad argument");
   return run_curl<1>(c, vorticity, forcing, prefactor);
-}
-
-// out = vorticity + p * curl(forcing) on the update set, vorticity elsewhere
-int smi_update_vorticity_into_impl(smi_ctx* c, void* out, const void* vorticity, void* forcing, double prefactor) {
-  return run_curl<2>(c, out, forcing, prefactor, vorticity);
 }
 
 // out = vorticity + p * curl(velocity x vorticity) on the update set, vorticity elsewhere

@@ -17,6 +17,7 @@ CASES = [
     ((8, 8, 8), 1),
     ((10, 9, 11), 2),   # px not a multiple of 4: scalar path
     ((12, 20, 36), 3),
+    ((36, 20, 300), 2),  # several LDS tiles along x (the last one partial), along y and three z chunks
 ]
 
 
