@@ -131,12 +131,43 @@ __device__ __forceinline__ int stage_pos(int u, int m) {
 // Per-thread stage twiddles (forward sign), loaded once per kernel from
 // tw4[k] = exp(-2 pi i k / (4L)).  Radix 8 keeps w, w^2, w^4 and forms the other powers
 // with four complex products.
+// Plans of four stages (L >= 1024) would hold ten complex stage twiddles per lane on top of the
+// transform's own registers; they keep them in an LDS table instead, indexed by k = j mod Ns:
+// radix 8 -> (w, w^2, w^4), radix 4 -> (w, w^2), radix 2 -> w, with w = w_{Ns R}^k.
+template <int LG>
+struct TwTab {
+  static constexpr bool USE = Plan<LG>::POW2 && LG >= 10;
+  static constexpr int per(int s) { return Plan<LG>::radix(s) == 8 ? 3 : (Plan<LG>::radix(s) == 4 ? 2 : 1); }
+  static constexpr int off(int s) {  // first entry of stage s
+    int o = 0;
+    for (int i = 1; i < s; ++i) o += per(i) * Plan<LG>::ns(i);
+    return o;
+  }
+  static constexpr int SIZE = USE ? off(Plan<LG>::NST) : 0;
+  // index into tw4[k] = exp(-2 pi i k / 4L) of w_{Ns R}: 4 L / (Ns R)
+  static constexpr int unit(int s) { return 4 * Plan<LG>::L / (Plan<LG>::ns(s) * Plan<LG>::radix(s)); }
+};
+
 template <typename T, int LG>
 struct Twiddles {
   Cx<T> w[Plan<LG>::NST > 1 ? Plan<LG>::NST : 1][4];
   const Cx<T>* mid;  // mixed plans: w_{8R}^{q k} = mid[q * mid_step], read from the table at each use
   int mid_step;
+  const Cx<T>* tab;  // TwTab plans: the LDS table
 };
+
+// Fills the LDS table; the first barrier of the first transform publishes it (stage 0 has no twiddles).
+template <typename T, int LG, int S>
+__device__ __forceinline__ void fill_tw_tab(Cx<T>* tab, const Cx<T>* __restrict__ tw4) {
+  if constexpr (TwTab<LG>::USE && S < Plan<LG>::NST) {
+    constexpr int per = TwTab<LG>::per(S), n = per * Plan<LG>::ns(S);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+      const int k = e / per, j = e - k * per;
+      tab[TwTab<LG>::off(S) + e] = tw4[(TwTab<LG>::unit(S) * k) << j];
+    }
+    fill_tw_tab<T, LG, S + 1>(tab, tw4);
+  }
+}
 
 template <typename T, int LG, int S>
 __device__ __forceinline__ void load_stage_tw(Twiddles<T, LG>& tw, int u, const Cx<T>* __restrict__ tw4) {
@@ -149,6 +180,8 @@ __device__ __forceinline__ void load_stage_tw(Twiddles<T, LG>& tw, int u, const 
     tw.w[2][0] = tw4[4 * ul];
     tw.w[2][1] = tw4[8 * ul];
     tw.w[2][2] = tw4[16 * ul];
+  } else if constexpr (TwTab<LG>::USE) {
+    // stage twiddles are read from the LDS table at each use
   } else if constexpr (S < Plan<LG>::NST) {
     if constexpr (S > 0) {
       constexpr int R = Plan<LG>::radix(S), Ns = Plan<LG>::ns(S), L = Plan<LG>::L, L8 = Plan<LG>::L8;
@@ -178,12 +211,26 @@ __device__ __forceinline__ Cx<T> sgn(Cx<T> w) {
   return SIGN > 0 ? Cx<T>{w.x, -w.y} : w;
 }
 
+// stage twiddle j of butterfly item q (registers, or the LDS table of the four-stage plans)
+template <int LG, int S, typename T>
+__device__ __forceinline__ Cx<T> stage_tw(const Twiddles<T, LG>& tw, int u, int q, int j) {
+  if constexpr (TwTab<LG>::USE) {
+    constexpr int Ns = Plan<LG>::ns(S), per = TwTab<LG>::per(S);
+    const int k = (u + q * Plan<LG>::L8) & (Ns - 1);
+    return tw.tab[TwTab<LG>::off(S) + per * k + j];
+  } else {
+    constexpr int R = Plan<LG>::radix(S);
+    return tw.w[S][R == 8 ? j : (R == 4 ? 2 * q + j : q)];
+  }
+}
+
 template <int SIGN, int LG, int S, typename T>
-__device__ __forceinline__ void butterflies(Cx<T> (&v)[8], const Twiddles<T, LG>& tw) {
+__device__ __forceinline__ void butterflies(Cx<T> (&v)[8], const Twiddles<T, LG>& tw, int u) {
   constexpr int R = Plan<LG>::radix(S);
   if constexpr (R == 8) {
     if constexpr (S > 0) {
-      const Cx<T> w1 = sgn<SIGN>(tw.w[S][0]), w2 = sgn<SIGN>(tw.w[S][1]), w4 = sgn<SIGN>(tw.w[S][2]);
+      const Cx<T> w1 = sgn<SIGN>(stage_tw<LG, S>(tw, u, 0, 0)), w2 = sgn<SIGN>(stage_tw<LG, S>(tw, u, 0, 1)),
+                  w4 = sgn<SIGN>(stage_tw<LG, S>(tw, u, 0, 2));
       const Cx<T> w3 = w1 * w2, w5 = w4 * w1, w6 = w4 * w2, w7 = w4 * w3;
       v[1] = v[1] * w1;
       v[2] = v[2] * w2;
@@ -198,7 +245,7 @@ __device__ __forceinline__ void butterflies(Cx<T> (&v)[8], const Twiddles<T, LG>
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if constexpr (S > 0) {
-        const Cx<T> w1 = sgn<SIGN>(tw.w[S][2 * q]), w2 = sgn<SIGN>(tw.w[S][2 * q + 1]);
+        const Cx<T> w1 = sgn<SIGN>(stage_tw<LG, S>(tw, u, q, 0)), w2 = sgn<SIGN>(stage_tw<LG, S>(tw, u, q, 1));
         v[q + 2] = v[q + 2] * w1;
         v[q + 4] = v[q + 4] * w2;
         v[q + 6] = v[q + 6] * (w1 * w2);
@@ -209,7 +256,7 @@ __device__ __forceinline__ void butterflies(Cx<T> (&v)[8], const Twiddles<T, LG>
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       Cx<T> b = v[q + 4];
-      if constexpr (S > 0) b = b * sgn<SIGN>(tw.w[S][q]);
+      if constexpr (S > 0) b = b * sgn<SIGN>(stage_tw<LG, S>(tw, u, q, 0));
       const Cx<T> a = v[q];
       v[q] = a + b;
       v[q + 4] = a - b;
@@ -222,9 +269,6 @@ constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per 
 
 #ifndef SMI_FFT_ZCOLS
 #define SMI_FFT_ZCOLS 0
-#endif
-#ifndef SMI_FFT_Z_LEAN
-#define SMI_FFT_Z_LEAN 1
 #endif
 #ifndef SMI_FFT_COLS_F32
 #define SMI_FFT_COLS_F32 16
@@ -295,7 +339,7 @@ __device__ __forceinline__ void fft_run_from(Cx<T> (&v)[8], TileSel<T, PP>& sel,
       for (int m = 0; m < 8; ++m) v[m] = r[LAY::idx(u + m * Plan<LG>::L8, t)];
       sel.after_read();
     }
-    butterflies<SIGN, LG, S>(v, tw);
+    butterflies<SIGN, LG, S>(v, tw, u);
     fft_run_from<SIGN, FIRST_FROM_LDS, LG, LAY, S + 1>(v, sel, t, u, tw);
   }
 }
@@ -502,7 +546,7 @@ struct TileCfg {
   static constexpr int WPE = sizeof(T) == 4 && !ROWS && TS * Plan<LG>::TPS >= 512 && Plan<LG>::POW2 ? 4 : 1;
   static constexpr int ELEMS = ROWS ? TS * PITCH : L * TS;               // one tile
   static constexpr bool PP = 2 * ELEMS * sizeof(Cx<T>) <= kLdsBudget;    // room for two tiles
-  static constexpr size_t BYTES = (PP ? 2 : 1) * ELEMS * sizeof(Cx<T>);
+  static constexpr size_t BYTES = ((PP ? 2 : 1) * ELEMS + TwTab<LG>::SIZE) * sizeof(Cx<T>);  // tiles, twiddle table
   using Lay = typename std::conditional<ROWS, RowLayout<PITCH>, ColLayout<TS>>::type;
   // column tiles per 128-byte line
   static constexpr int PF = (!ROWS && TS * sizeof(Cx<T>) < 128) ? 128 / (TS * (int)sizeof(Cx<T>)) : 1;
@@ -521,6 +565,8 @@ struct TileCfg {
   const int u = ROWS ? threadIdx.x % Cfg::TPS : threadIdx.x / TS;                      \
   const bool item = Plan<LG>::POW2 || u < L8; /* lanes beyond the work items only serve the middle stage */ \
   Twiddles<T, LG> tw;                                                                  \
+  tw.tab = reinterpret_cast<Cx<T>*>(smem) + (Cfg::PP ? 2 : 1) * Cfg::ELEMS;            \
+  fill_tw_tab<T, LG, 1>(const_cast<Cx<T>*>(tw.tab), tw4);                              \
   load_stage_tw<T, LG, 0>(tw, u, tw4);                                                 \
   const Cx<T> wu = tw4[2 * u]; /* exp(-i pi u / L) */                                  \
   (void)L; (void)wu; (void)item;
@@ -534,9 +580,8 @@ struct TileCfg {
 // are transformed along with the rest (finite garbage that nothing reads) and no lane is
 // predicated off.
 
-// The z convolution holds three register sets (transform, even-parity result, prefetched next
-// column).  The mixed plans add the middle-stage operands on top, which does not fit 128
-// registers: their tiles are 8 columns wide, hence at most 512 lanes and 256 registers.
+// Tile shape of the z convolution: that of the y kernels unless SMI_FFT_ZCOLS asks for another
+// width (8-column tiles, i.e. two 512-lane workgroups per CU, measured slower at every length).
 template <typename T, int LG>
 using ZCfg = TileCfg<T, LG, false, SMI_FFT_ZCOLS>;
 
@@ -684,10 +729,11 @@ __global__ void __launch_bounds__((ZCfg<T, LG>::NT), (ZCfg<T, LG>::WPE))
     k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
   using ZC_ = ZCfg<T, LG>;
   FFT_KERNEL_PROLOGUE_T(false, ZC_)
-  // Plans beyond 512 points and the mixed ones do not fit the register file with the Green's
-  // values of both parities held across tiles and the next column requested two transforms
-  // ahead: they reload the former per tile and request the latter one transform ahead.
-  constexpr bool LEAN = SMI_FFT_Z_LEAN && (SMI_FFT_Z_LEAN > 1 || !(Plan<LG>::POW2 && LG <= 9));
+  // The mixed plans add their middle-stage operands to the three register sets of this kernel and
+  // do not fit 128 registers with the Green's values of both parities held across tiles and the
+  // next column requested two transforms ahead: they reload the former per tile and request the
+  // latter one transform ahead.
+  constexpr bool LEAN = !Plan<LG>::POW2;
   int ct, kyc, k;
   if (!col_tile<Cfg::PF>(G, ct, kyc, k)) return;
   const int col = ct * TS + t;
