@@ -336,36 +336,62 @@ __device__ __forceinline__ double block_reduce(double v, bool is_max, double* sh
   return r;  // valid in thread 0
 }
 
+// One pass over the interior of a field (or of a vector field's three components at once for
+// the CFL quantity).  A workgroup takes kRedRows rows per trip, so that each lane has up to a
+// dozen independent loads in flight; maxima are taken in the field's own type (exact), squares
+// are summed in double.
+constexpr int kRedRows = 4;
+
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) k_reduce_rows(const T* __restrict__ f, int ncomp, int nz, int ny,
                                                      int nx, int g, int px, size_t plane, size_t vol,
                                                      double* __restrict__ partials) {
   __shared__ double sh[4];
   constexpr bool is_max = MODE != RED_SUM_SQ;
-  double acc = is_max ? -INFINITY : 0.0;
-  size_t rows = (size_t)nz * ny * (MODE == RED_MAX_ABS_SUM3 ? 1 : ncomp);
-  for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
-    size_t r = row;
-    int comp = 0;
-    if (MODE != RED_MAX_ABS_SUM3) {
-      comp = (int)(r / ((size_t)nz * ny));
-      r -= (size_t)comp * nz * ny;
+  T amax = -INFINITY;
+  double asum = 0.0;
+  const size_t rows = (size_t)nz * ny * (MODE == RED_MAX_ABS_SUM3 ? 1 : ncomp);
+  for (size_t row0 = (size_t)blockIdx.x * kRedRows; row0 < rows; row0 += (size_t)gridDim.x * kRedRows) {
+    const T* base[kRedRows];
+#pragma unroll
+    for (int j = 0; j < kRedRows; ++j) {
+      // rows past the end repeat the last one: harmless for a maximum, skipped for the sum
+      size_t r = row0 + j < rows ? row0 + j : rows - 1;
+      int comp = 0;
+      if (MODE != RED_MAX_ABS_SUM3) {
+        comp = (int)(r / ((size_t)nz * ny));
+        r -= (size_t)comp * nz * ny;
+      }
+      const int z = (int)(r / ny) + g, y = (int)(r % ny) + g;
+      base[j] = f + (size_t)comp * vol + (size_t)z * plane + (size_t)y * px + g;
     }
-    int z = (int)(r / ny) + g, y = (int)(r % ny) + g;
-    const T* base = f + (size_t)comp * vol + (size_t)z * plane + (size_t)y * px + g;
     for (int x = threadIdx.x; x < nx; x += blockDim.x) {
       if (MODE == RED_MAX_ABS_SUM3) {
-        T s = fabs(base[x]) + fabs(base[vol + x]) + fabs(base[2 * vol + x]);
-        acc = fmax(acc, (double)s);
-      } else if (MODE == RED_MAX) {
-        acc = fmax(acc, (double)base[x]);
+        T a[kRedRows], b[kRedRows], c[kRedRows];
+#pragma unroll
+        for (int j = 0; j < kRedRows; ++j) {
+          a[j] = base[j][x];
+          b[j] = base[j][vol + x];
+          c[j] = base[j][2 * vol + x];
+        }
+#pragma unroll
+        for (int j = 0; j < kRedRows; ++j) amax = fmax(amax, fabs(a[j]) + fabs(b[j]) + fabs(c[j]));
       } else {
-        double v = (double)base[x];
-        acc += v * v;
+        T a[kRedRows];
+#pragma unroll
+        for (int j = 0; j < kRedRows; ++j) a[j] = base[j][x];
+#pragma unroll
+        for (int j = 0; j < kRedRows; ++j) {
+          if (MODE == RED_MAX) {
+            amax = fmax(amax, a[j]);
+          } else if (row0 + j < rows) {
+            asum += (double)a[j] * (double)a[j];
+          }
+        }
       }
     }
   }
-  double r = block_reduce(acc, is_max, sh);
+  double r = block_reduce(is_max ? (double)amax : asum, is_max, sh);
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
@@ -383,8 +409,9 @@ template <int MODE>
 static int run_reduce(smi_ctx* c, const void* field, int ncomp, double* out) {
   SMI_REQUIRE(c && field && out, "smi_reduce: bad argument");
   double* partials = (double*)c->red_partials;
-  size_t rows = (size_t)c->nz * c->ny * (MODE == RED_MAX_ABS_SUM3 ? 1 : ncomp);
-  int blocks = (int)(rows < (size_t)kRedBlocks ? rows : kRedBlocks);
+  const size_t rows = (size_t)c->nz * c->ny * (MODE == RED_MAX_ABS_SUM3 ? 1 : ncomp);
+  const size_t trips = (rows + kRedRows - 1) / kRedRows;
+  int blocks = (int)(trips < (size_t)kRedBlocks ? trips : kRedBlocks);
   SMI_DISPATCH(c, {
     k_reduce_rows<T, MODE><<<blocks, 256, 0, c->stream>>>((const T*)field, ncomp, c->nz, c->ny, c->nx, c->g,
                                                           c->px, c->plane, c->vol, partials);
