@@ -20,6 +20,19 @@ extern "C" int smi_device_count(int* count) {
   return 0;
 }
 
+// streams, events and the small device / pinned buffers of a context whose sizes are set
+static int ctx_allocate(smi_ctx* c) {
+  SMI_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  SMI_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+  SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+  SMI_CHECK_HIP(hipMalloc(&c->red_partials, sizeof(double) * (kRedBlocks + 8)));
+  SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, sizeof(double) * 8, hipHostMallocDefault));
+  SMI_CHECK_HIP(hipMalloc(&c->fac_dev, sizeof(double) * 6 * 64));
+  for (int i = 0; i < 2; ++i) SMI_CHECK_HIP(hipMalloc(&c->halo_recv[i], c->halo_cap));
+  return 0;
+}
+
 extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost,
                               int rank, int nranks) {
   SMI_REQUIRE(out, "smi_ctx_create: null output");
@@ -49,16 +62,13 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   c->nranks = nranks;
   c->phys_zlo = rank == 0;
   c->phys_zhi = rank == nranks - 1;
-  SMI_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  SMI_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
-  SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
-  SMI_CHECK_HIP(hipMalloc(&c->red_partials, sizeof(double) * (kRedBlocks + 8)));
-  SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, sizeof(double) * 8, hipHostMallocDefault));
-  SMI_CHECK_HIP(hipMalloc(&c->fac_dev, sizeof(double) * 6 * 64));
   // staging for the ghost sum (and the host-staged plane upload): 3 components of g planes
   c->halo_cap = (size_t)3 * ghost * c->plane * smi_elem_size(c);
-  for (int i = 0; i < 2; ++i) SMI_CHECK_HIP(hipMalloc(&c->halo_recv[i], c->halo_cap));
+  const int rc = ctx_allocate(c);
+  if (rc) {
+    smi_ctx_destroy(c);  // releases whatever was created before the failure
+    return rc;
+  }
   *out = c;
   return 0;
 }
@@ -66,20 +76,20 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
 extern "C" int smi_ctx_destroy(smi_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  hipStreamSynchronize(c->comm_stream);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
   if (c->comm_ready) ncclCommDestroy(c->comm);
   for (int i = 0; i < 2; ++i) {
     if (c->halo_recv[i]) hipFree(c->halo_recv[i]);
   }
   delete c->prof;
-  hipFree(c->red_partials);
-  hipFree(c->fac_dev);
-  hipHostFree(c->red_host);
-  hipEventDestroy(c->ev_a);
-  hipEventDestroy(c->ev_b);
-  hipStreamDestroy(c->stream);
-  hipStreamDestroy(c->comm_stream);
+  if (c->red_partials) hipFree(c->red_partials);
+  if (c->fac_dev) hipFree(c->fac_dev);
+  if (c->red_host) hipHostFree(c->red_host);
+  if (c->ev_a) hipEventDestroy(c->ev_a);
+  if (c->ev_b) hipEventDestroy(c->ev_b);
+  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->comm_stream) hipStreamDestroy(c->comm_stream);
   delete c;
   return 0;
 }

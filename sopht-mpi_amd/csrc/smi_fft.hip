@@ -1023,6 +1023,22 @@ static int set_lds(const void* fn, size_t bytes) {
   return 0;
 }
 
+// full-spectrum Green's function (device, c64 / c128) -> the folded real table of the z convolution
+static int fold_greens_table(smi_ctx* c, PrunedState* s, const void* ghat) {
+  const PGeo& G = s->G;
+  s->green_bytes = (size_t)(G.nz + 1) * (G.ny + 1) * G.KXP * smi_elem_size(c);
+  SMI_CHECK_HIP(hipMalloc(&s->green, s->green_bytes));
+  const long long total = (long long)(G.nz + 1) * (G.ny + 1) * G.KXP;
+  const double norm = 1.0 / (4.0 * (double)G.nx * (double)G.ny * (double)G.nz);
+  SMI_DISPATCH(c, {
+    k_fold_green<T><<<(int)((total + kThreads - 1) / kThreads), kThreads, 0, c->stream>>>((T*)s->green, (const T*)ghat,
+                                                                                         G, c->rank, (T)norm);
+  });
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int smi_pruned_create(smi_poisson* p) {
   smi_ctx* c = p->ctx;
   SMI_REQUIRE(p->gnx % 2 == 0 && plan_key(p->gnx / 2) && plan_key(p->gny) && plan_key(p->gnz) && p->gnx >= 16 &&
@@ -1077,18 +1093,9 @@ int smi_pruned_create(smi_poisson* p) {
   // Green's table: full spectrum once through rocFFT, then fold / permute / normalise
   void* ghat = nullptr;
   SMI_CHECK(smi_greens_spectrum_rocfft(c, G.nz, G.ny, G.nx, p->dx, p->x_range, &ghat));
-  s->green_bytes = (size_t)(G.nz + 1) * (G.ny + 1) * G.KXP * smi_elem_size(c);
-  SMI_CHECK_HIP(hipMalloc(&s->green, s->green_bytes));
-  const long long total = (long long)(G.nz + 1) * (G.ny + 1) * G.KXP;
-  const double norm = 1.0 / (4.0 * (double)G.nx * (double)G.ny * (double)G.nz);
-  SMI_DISPATCH(c, {
-    k_fold_green<T><<<(int)((total + kThreads - 1) / kThreads), kThreads, 0, c->stream>>>((T*)s->green, (const T*)ghat,
-                                                                                         G, c->rank, (T)norm);
-  });
-  SMI_LAUNCH_CHECK();
-  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
-  SMI_CHECK_HIP(hipFree(ghat));
-  return 0;
+  const int rc = fold_greens_table(c, s, ghat);
+  hipFree(ghat);  // also when the fold failed
+  return rc;
 }
 
 size_t smi_pruned_greens_size(smi_poisson* p) { return p->pruned ? p->pruned->green_bytes : 0; }

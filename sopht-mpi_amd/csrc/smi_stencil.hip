@@ -1080,12 +1080,12 @@ TiledLaunch tiled_launch(const smi_ctx* c, int ncomp_lds, int grid_z) {
   t.lds_bytes = (size_t)2 * ncomp_lds * (t.S.rows + 2) * t.S.pitch * sizeof(T);  // two spare rows per tile
   return t;
 }
+// The tiled kernels may need more than the default 64 KB of dynamic LDS (double precision).  The
+// attribute belongs to the current device's copy of the function, so it is set before every
+// launch rather than cached per process: a process may hold contexts on several devices.
 template <typename F>
-int allow_lds(F fn, bool& done) {
-  if (!done) {
-    SMI_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    done = true;
-  }
+int allow_lds(F fn) {
+  SMI_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   return 0;
 }
 
@@ -1101,8 +1101,7 @@ extern "C" int smi_diffusion_flux(smi_ctx* c, void* flux, const void* field, dou
   SMI_DISPATCH(c, {
     if (vec_ok<T>(c, flux, field)) {
       const TiledLaunch t = tiled_launch<T>(c, 1, ncomp);
-      static bool attr = false;
-      SMI_CHECK(allow_lds(k_diffuse_tiled<T, false>, attr));
+      SMI_CHECK(allow_lds(k_diffuse_tiled<T, false>));
       k_diffuse_tiled<T, false><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)flux, (const T*)field, (T)prefactor,
                                                                               G, t.zchunk, t.S);
     } else {
@@ -1133,8 +1132,7 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
   SMI_DISPATCH(c, {
     if (vec_ok<T>(c, out, in)) {
       const TiledLaunch t = tiled_launch<T>(c, 1, ncomp);
-      static bool attr = false;
-      SMI_CHECK(allow_lds(k_diffuse_tiled<T, true>, attr));
+      SMI_CHECK(allow_lds(k_diffuse_tiled<T, true>));
       k_diffuse_tiled<T, true><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)in, (T)prefactor, G,
                                                                              t.zchunk, t.S);
     } else {
@@ -1155,8 +1153,7 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor) {
   SMI_DISPATCH(c, {
     if (MODE == 0 && vec_ok<T>(c, out, f)) {
       const TiledLaunch t = tiled_launch<T>(c, 3, 1);
-      static bool attr = false;
-      SMI_CHECK(allow_lds(k_curl_tiled<T>, attr));
+      SMI_CHECK(allow_lds(k_curl_tiled<T>));
       k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S);
     } else if (vec_ok<T>(c, out, f)) {
       LaunchShape s = plan<4>(c, 1);
@@ -1189,12 +1186,7 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
     if (vec_ok<T>(c, out, velocity) && vec_ok<T>(c, out, vorticity)) {
       const TileShape S = tile_shape<T>(c);
       const size_t lds_bytes = (size_t)2 * 3 * S.rows * S.pitch * sizeof(T);
-      static bool attr_set = false;
-      if (!attr_set) {
-        SMI_CHECK_HIP(hipFuncSetAttribute((const void*)k_advect_tiled<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          128 * 1024));
-        attr_set = true;
-      }
+      SMI_CHECK(allow_lds(k_advect_tiled<T>));
       // short z chunks (two halo planes per 16) measured faster than long ones: more, shorter workgroups
       int zchunk = c->pz < 16 ? c->pz : 16;
       dim3 grid(S.ntx * S.nty, (c->pz + zchunk - 1) / zchunk, 1);
