@@ -1060,9 +1060,21 @@ int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 #ifndef SMI_TILE_ZCHUNK
 #define SMI_TILE_ZCHUNK 16
 #endif
+#ifndef SMI_TILE_MIN_WGS
+#define SMI_TILE_MIN_WGS 4096
+#endif
 #ifndef SMI_TILE_ROWS
 #define SMI_TILE_ROWS 8
 #endif
+// Planes per workgroup of a tiled kernel.  Each chunk re-reads two halo planes, so chunks are
+// SMI_TILE_ZCHUNK planes long unless that leaves the chip (1024 - 2048 resident workgroups)
+// with fewer than a few rounds of work: then they are halved once (256^3: advection 0.195 -> 0.163 ms).
+static int tiled_zchunk(const smi_ctx* c, int tiles_per_plane_set) {
+  int zchunk = SMI_TILE_ZCHUNK;
+  while (zchunk > 8 && (long long)tiles_per_plane_set * ((c->pz + zchunk - 1) / zchunk) < SMI_TILE_MIN_WGS) zchunk /= 2;
+  return c->pz < zchunk ? c->pz : zchunk;
+}
+
 // launch geometry of the LDS-tiled stencil kernels (ncomp_lds component tiles, two buffers)
 struct TiledLaunch {
   TileShape S;
@@ -1074,7 +1086,7 @@ template <typename T>
 TiledLaunch tiled_launch(const smi_ctx* c, int ncomp_lds, int grid_z) {
   TiledLaunch t;
   t.S = tile_shape<T>(c, SMI_TILE_ROWS);
-  t.zchunk = c->pz < SMI_TILE_ZCHUNK ? c->pz : SMI_TILE_ZCHUNK;
+  t.zchunk = tiled_zchunk(c, t.S.ntx * t.S.nty * grid_z);
   t.grid = dim3(t.S.ntx * t.S.nty, (c->pz + t.zchunk - 1) / t.zchunk, grid_z);
   t.threads = (t.S.txl * t.S.ty + 63) / 64 * 64;  // whole waves covering the tile and its halo duty
   t.lds_bytes = (size_t)2 * ncomp_lds * (t.S.rows + 2) * t.S.pitch * sizeof(T);  // two spare rows per tile
@@ -1188,7 +1200,7 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
       const size_t lds_bytes = (size_t)2 * 3 * S.rows * S.pitch * sizeof(T);
       SMI_CHECK(allow_lds(k_advect_tiled<T>));
       // short z chunks (two halo planes per 16) measured faster than long ones: more, shorter workgroups
-      int zchunk = c->pz < 16 ? c->pz : 16;
+      const int zchunk = tiled_zchunk(c, S.ntx * S.nty);
       dim3 grid(S.ntx * S.nty, (c->pz + zchunk - 1) / zchunk, 1);
       const int threads = (S.txl * S.ty + 63) / 64 * 64;  // whole waves covering the tile and its halo duty
       k_advect_tiled<T><<<grid, threads, lds_bytes, c->stream>>>((T*)out, (const T*)velocity,
