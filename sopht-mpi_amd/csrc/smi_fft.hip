@@ -25,6 +25,7 @@
 // rank a contiguous kx range for ALL z (before any y / z padding exists), y and z passes
 // run locally, a second all-to-all goes back.  x_fwd writes and x_inv reads the exchange
 // layout directly, so there is no pack / unpack pass.
+#include <cstdlib>
 #include <vector>
 
 #include "smi_common.h"
@@ -493,18 +494,24 @@ __device__ __forceinline__ Cx<T> mul_c16(Cx<T> w, int m) {
 constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 
 // Geometry of the spectral buffers.
-//   bufA (exchange layout) : [comp][rank P][z nzl][y ny][KXP]         x_fwd out, x_inv in
-//   bufT (after all-to-all): [comp][slab P][z nzl][y ny][KXP]         y_fwd in, y_inv out
-//                            = [comp][z nz][y ny][KXP]; one component's rank blocks are
+//   bufA (exchange layout) : [comp][rank P][z nzl][y ny][KXA]         x_fwd out, x_inv in
+//   bufT (after all-to-all): [comp][slab P][z nzl][y ny][KXA]         y_fwd in, y_inv out
+//                            = [comp][z nz][y ny][KXA]; one component's rank blocks are
 //                            contiguous, so every component is exchanged on its own
 //   bufB                   : [comp nc][z / ZB][ky' 2ny][z % ZB][KXP]   z_conv in place; blocked in z so
 //                            that neither a y tile (all ky' of one z) nor a z tile (all z of one
 //                            ky') strides over more than a few dozen pages
 //   green                  : [ky folded ny+1][kz folded nz+1][KXP]    real
 // KXL = spectral columns per rank (kx in parity-split order j = 0..nx, cut into P ranges),
-// KXP = row pitch (KXL rounded up to 16 columns).
+// KXP = row pitch of bufB and of the Green's table (KXL rounded up to 16 columns: whole 128-byte
+// lines).  KXA = row pitch of the exchange buffers: KXP on one rank; KXL across ranks, where
+// every pad column would travel through both all-to-alls (19 % of their bytes at 8 ranks) and the
+// links, not the kernels, set the pace.  The y kernels then read rows of bufT past their end (the
+// next row's first columns stand in for the pad columns of a tile: finite values that only reach
+// pad columns of bufB) and store only columns below KXL; their partial-line stores cost
+// k_fft_y_inv 66 % on one GPU, which is why a single rank keeps the padded pitch.
 struct PGeo {
-  int nz, ny, nx, nzl, P, nc, KXL, KXP, zb_shift;
+  int nz, ny, nx, nzl, P, nc, KXL, KXP, KXA, zb_shift;
   int c0;  // first component of this launch (components c0 .. c0 + nc - 1)
   int nct, n2, n3;  // column kernels: tiles per row, second and third extent of the launch
   int zg;           // y kernels: consecutive planes one workgroup walks over
@@ -615,11 +622,11 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
   const int col = ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
-  const unsigned off_in = (unsigned)u * G.KXP + col, off_out = (unsigned)u * kystride + col;
+  const unsigned off_in = (unsigned)u * G.KXA + col, off_out = (unsigned)u * kystride + col;
   auto src_of = [&](int it) {
     int c, z;
     W.tile(G, it, c, z);
-    return in + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
+    return in + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXA;
   };
   auto dst_of = [&](int it) {
     int c, z;
@@ -631,7 +638,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
   {
     const Cx<T>* src = src_of(0);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) a0[m] = ok ? (src + (size_t)(m * L8) * G.KXP)[off_in] : Cx<T>{0, 0};
+    for (int m = 0; m < 8; ++m) a0[m] = ok ? (src + (size_t)(m * L8) * G.KXA)[off_in] : Cx<T>{0, 0};
   }
   for (int it = 0; it < W.ntile; ++it) {
     Cx<T>* dst = dst_of(it);
@@ -642,7 +649,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
       for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
       if (parity == 1 && it + 1 < W.ntile) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) a0[m] = ok ? (nsrc + (size_t)(m * L8) * G.KXP)[off_in] : Cx<T>{0, 0};
+        for (int m = 0; m < 8; ++m) a0[m] = ok ? (nsrc + (size_t)(m * L8) * G.KXA)[off_in] : Cx<T>{0, 0};
       }
       fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
       if (ok) {
@@ -664,7 +671,8 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
   const int col = ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
-  const unsigned off_in = (unsigned)u * kystride + col, off_out = (unsigned)u * G.KXP + col;
+  const unsigned off_in = (unsigned)u * kystride + col, off_out = (unsigned)u * G.KXA + col;
+  const bool st_ok = ok && col < G.KXA;  // a tile's pad columns lie in the next row of a tightly pitched bufT
   auto src_of = [&](int it) {
     int c, z;
     W.tile(G, it, c, z);
@@ -673,7 +681,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
   auto dst_of = [&](int it) {
     int c, z;
     W.tile(G, it, c, z);
-    return out + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXP;
+    return out + (((size_t)c * G.nz + z) * G.ny) * (size_t)G.KXA;
   };
   // x0 / x1: even / odd half of the spectrum of the tile about to be transformed; each is
   // requested again for the next tile as soon as it has been copied out
@@ -706,9 +714,9 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
       for (int m = 0; m < 8; ++m) x1[m] = ok ? (nsrc + (size_t)(L + m * L8) * kystride)[off_in] : Cx<T>{0, 0};
     }
     fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
-    if (ok) {
+    if (st_ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) (dst + (size_t)(m * L8) * G.KXP)[off_out] = res[m] + conj(mul_c16(wu, m)) * v[m];
+      for (int m = 0; m < 8; ++m) (dst + (size_t)(m * L8) * G.KXA)[off_out] = res[m] + conj(mul_c16(wu, m)) * v[m];
     }
   }
 }
@@ -849,8 +857,8 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
   const bool ok = y < G.ny && item;
   const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
-  const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXP;
-  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
+  const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
+  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
   const Cx<T> w1 = tw4[1];  // exp(-i pi / 2L)
   Cx<T> v[8], a0[8];
 #pragma unroll
@@ -899,8 +907,8 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
   const bool ok = y < G.ny && item;
   T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
-  const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXP;
-  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXP;
+  const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
+  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
   const Cx<T> w1 = tw4[1];
   Cx<T> v[8], res[8];
 #pragma unroll
@@ -1059,6 +1067,8 @@ int smi_pruned_create(smi_poisson* p) {
   G.c0 = 0;
   G.KXL = (G.nx + 1 + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
+  // SMI_FFT_TIGHT_PITCH: the tight exchange pitch on a single rank as well (tests, measurements)
+  G.KXA = (G.P > 1 || getenv("SMI_FFT_TIGHT_PITCH")) ? G.KXL : G.KXP;
   // z blocks of at most 16 planes and at most nz / 8 (one work item's elements share z % ZB)
   G.zb_shift = 0;  // largest power of two <= 16 that divides nz / 8
   while (G.zb_shift < 4 && (G.nz / 8) % (2 << G.zb_shift) == 0) ++G.zb_shift;
@@ -1066,7 +1076,7 @@ int smi_pruned_create(smi_poisson* p) {
   s->lgy = plan_key(G.ny);
   s->lgz = plan_key(G.nz);
   const size_t cs = 2 * smi_elem_size(c);
-  const size_t nA = (size_t)G.P * G.nc * G.nzl * G.ny * G.KXP;
+  const size_t nA = (size_t)G.P * G.nc * G.nzl * G.ny * G.KXA + 16;  // + what the last row's tile reads past it
   const size_t nB = (size_t)G.nc * G.nz * 2 * G.ny * G.KXP;
   // the column kernels index one workgroup's tile with 32-bit element offsets
   SMI_REQUIRE((size_t)G.nz * 2 * G.ny * G.KXP / 8 < (1ull << 32) && (size_t)(2 * G.nz + 2) * G.KXP < (1ull << 32) &&
@@ -1202,7 +1212,7 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
   // -> x_inv(k).  With RCCL the transposes go to the communication stream and events carry the
   // dependencies, so that a transpose overlaps the transforms of the neighbouring components;
   // a host-staged transport (callback) is synchronous and everything stays on one stream.
-  const size_t peer_bytes = (size_t)G.nzl * G.ny * G.KXP * cs;   // one component, one peer
+  const size_t peer_bytes = (size_t)G.nzl * G.ny * G.KXA * cs;   // one component, one peer
   const size_t comp_bytes = peer_bytes * G.P;
   const bool overlap = !c->alltoall_cb;
   hipStream_t cstream = overlap ? s->comm_stream : c->stream;

@@ -66,6 +66,17 @@ def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
     smi._lib.call("smi_poisson_destroy", h)
 
 
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,g", [((16, 16, 16), 2), ((8, 16, 32), 1), ((32, 64, 32), 2), ((8, 192, 384), 2),
+                                     ((64, 32, 128), 2)])
+def test_poisson_tight_exchange_pitch(smi, shape, g, real_t, monkeypatch):
+    """The exchange buffers of multi-rank runs have a row pitch of exactly the spectral columns a
+    rank owns (rows no longer start on 128-byte lines, tiles read past row ends); the same
+    layout forced on a single rank must give the same answers."""
+    monkeypatch.setenv("SMI_FFT_TIGHT_PITCH", "1")
+    test_poisson_solve_matches_oracle(smi, shape, g, real_t, "pruned")
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_poisson_linearity_and_point_source(smi, backend):
     """Size-independent properties: linearity, and the response to a unit point source is the
