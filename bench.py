@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 ALG_BYTES_PER_POINT_STEP = 1692.0
 MIN_BYTES_PER_POINT_STEP = 660.0
 IMPL_BYTES_PER_POINT_STEP = 408.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_counters_512cubed_v4.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_counters_512cubed_v5.json")
 
 
 def synthetic_vorticity(position_field, real_t, seed=0, nblobs=8, sigma=0.05):
@@ -138,8 +138,8 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--poisson", default=None, choices=[None, "rocfft", "pruned"])
-    ap.add_argument("--cpu-grid", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-grid", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -11,7 +11,6 @@ import logging
 
 import numpy as np
 
-from ... import _lib
 from ..._lib import call, darray
 from ...device import as_ptr
 from ...numeric.eulerian_grid_ops import (

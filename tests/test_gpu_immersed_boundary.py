@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import assert_close, make_ctx, rand_field
+from helpers import assert_close, rand_field
 from oracle import immersed_boundary as oib
 
 pytestmark = pytest.mark.gpu
