@@ -135,6 +135,12 @@ int smi_diffusion_timestep(smi_ctx* ctx, void* field, void* flux, double nu_dt_b
  * update_vorticity_from_velocity_forcing_mpi_3d.py:9-178 */
 int smi_update_vorticity_from_velocity_forcing(smi_ctx* ctx, void* vorticity, void* forcing,
                                                double prefactor);
+/* The rotational-form advection of rotational_form_navier_stokes_timestep in one pass
+ * (flow_simulators_mpi_3d.py:395-405: elementwise_cross_product(buffer, velocity, vorticity) then
+ * update_vorticity_from_velocity_forcing(vorticity, buffer, dt / (2 dx))), written to another array:
+ * out = vorticity + prefactor * curl(velocity x vorticity) on the cells the update writes,
+ * out = vorticity elsewhere.  `out` must not alias the inputs; all three are vector fields. */
+int smi_rotational_advection_update(smi_ctx* ctx, void* out, void* velocity, void* vorticity, double prefactor);
 /* gen_curl_pyst_mpi_kernel_3d, curl_mpi_3d.py:10-196 */
 int smi_curl(smi_ctx* ctx, void* curl, void* field, double prefactor);
 /* gen_divergence_pyst_mpi_kernel_3d, divergence_mpi_3d.py:10-200 */

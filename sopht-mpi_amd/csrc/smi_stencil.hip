@@ -1215,6 +1215,12 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
   return 0;
 }
 
+extern "C" int smi_rotational_advection_update(smi_ctx* c, void* out, void* velocity, void* vorticity,
+                                               double prefactor) {
+  SMI_REQUIRE(c && out && velocity && vorticity, "smi_rotational_advection_update: bad argument");
+  return smi_advect_vorticity_impl(c, out, velocity, vorticity, prefactor);
+}
+
 extern "C" int smi_curl(smi_ctx* c, void* curl, void* field, double prefactor) {
   SMI_REQUIRE(c && curl && field, "smi_curl: bad argument");
   return run_curl<0>(c, curl, field, prefactor);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "smi_penalise_boundary": [_p, _p, _i, _i, _dp, _dp],
     "smi_laplacian_filter": [_p, _p, _i, _p, _p, _i, _i],
     "smi_advection_timestep_eno3": [_p, _p, _p, _p, _d, _i],
+    "smi_rotational_advection_update": [_p, _p, _p, _p, _d],
     "smi_reduce_max_abs_sum": [_p, _p, _dp],
     "smi_reduce_max": [_p, _p, _i, _dp],
     "smi_reduce_sum_sq": [_p, _p, _i, _dp],
