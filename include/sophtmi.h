@@ -253,6 +253,12 @@ int smi2d_reduce_max(smi_ctx* ctx, const void* field, double* out);
 int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* ctx, const void* greens_host, double dx);
 int smi2d_poisson_destroy(smi_poisson2d* p);
 int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void* rhs);
+/* UnboundedFlowSimulator2D.navier_stokes_timestep / navier_stokes_with_forcing_timestep,
+ * flow_simulators_mpi_2d.py:260-298, as one call: forcing may be NULL (no forcing update), free_stream
+ * NULL (no free stream), fac_lo / fac_hi as for smi2d_penalise_boundary (ignored when the width is 0). */
+int smi2d_flow_step_ns(smi_ctx* ctx, smi_poisson2d* p, void* vorticity, void* velocity, void* stream_func,
+                       void* buffer_scalar, void* forcing, double dt, double nu, double dx, int penalty_width,
+                       const double* fac_lo, const double* fac_hi, const double* free_stream);
 /* immersed_boundary_ops/EulerianLagrangianGridCommunicatorMPI2D.py:116-520: support (2,4,4,M) and
  * nearest index (2,M) of the nodes, delta-function weights (4,4,M), Eulerian -> Lagrangian
  * interpolation, Lagrangian -> Eulerian spreading (ghost_sum != 0: followed by the ghost sum of

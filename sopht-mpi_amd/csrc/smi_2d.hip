@@ -615,3 +615,27 @@ extern "C" int smi2d_ib_spread(smi_ctx* c, void* eul_field, const void* lag_fiel
   SMI_LAUNCH_CHECK();
   return 0;
 }
+
+// One 2D Navier-Stokes step sequenced inside the library (flow_simulators_mpi_2d.py:260-298): the
+// forcing update, ENO3 advection, diffusion, penalisation, Poisson solve, curl and free stream,
+// one host call instead of seven: the 256^2 step is bound by launch and call overhead.
+extern "C" int smi2d_flow_step_ns(smi_ctx* c, smi_poisson2d* p, void* vorticity, void* velocity, void* stream_func,
+                                  void* buffer_scalar, void* forcing, double dt, double nu, double dx,
+                                  int penalty_width, const double* fac_lo, const double* fac_hi,
+                                  const double* free_stream) {
+  SMI_REQUIRE(c && p && vorticity && velocity && stream_func && buffer_scalar, "smi2d_flow_step_ns: null argument");
+  // prefactors rounded to the real type exactly as the reference does with real_t(...)
+  auto r = [&](double v) { return c->dtype == SMI_F32 ? (double)(float)v : v; };
+  if (forcing) SMI_CHECK(smi2d_update_vorticity_from_velocity_forcing(c, vorticity, forcing, r(dt / (2 * dx))));
+  SMI_CHECK(smi2d_advection_timestep_eno3(c, vorticity, buffer_scalar, velocity, r(dt / dx)));
+  SMI_CHECK(smi2d_diffusion_timestep(c, vorticity, buffer_scalar, r(nu * dt / dx / dx)));
+  if (penalty_width > 0) SMI_CHECK(smi2d_penalise_boundary(c, vorticity, penalty_width, fac_lo, fac_hi));
+  SMI_CHECK(smi2d_poisson_solve(p, stream_func, vorticity));
+  SMI_CHECK(smi2d_outplane_field_curl(c, velocity, stream_func, r(0.5 / dx)));
+  if (free_stream) SMI_CHECK(smi2d_add_fixed_val(c, velocity, velocity, 2, free_stream));
+  if (forcing) {
+    const double z2[2] = {0.0, 0.0};
+    SMI_CHECK(smi2d_set_fixed_val(c, forcing, 2, z2));
+  }
+  return 0;
+}

@@ -108,6 +108,7 @@ def gen_penalise_field_boundary_pyst_mpi_kernel_2d(width, dx, x_grid_field, y_gr
         call("smi2d_penalise_boundary", ctx.handle, as_ptr(field), int(width), lo_c, hi_c)
 
     penalise_field_boundary_pyst_mpi_kernel_2d.kernel_support = 0
+    penalise_field_boundary_pyst_mpi_kernel_2d.factor_tables = (lo_c, hi_c)  # for the fused step
     return penalise_field_boundary_pyst_mpi_kernel_2d
 
 

@@ -5,7 +5,7 @@ import logging
 
 import numpy as np
 
-from ..._lib import call
+from ..._lib import call, darray
 from ...device import as_ptr
 from ...numeric.eulerian_grid_ops import (
     UnboundedPoissonSolverMPI2D,
@@ -45,6 +45,9 @@ class UnboundedFlowSimulator2D:
         self.rank_distribution = rank_distribution
         self.ghost_size = ghost_size
         self._world = kwargs.get("world", None)
+        # True: one library call per Navier-Stokes step (smi2d_flow_step_ns); False: the reference's
+        # operator-by-operator sequence
+        self.fused_step = kwargs.get("fused_step", True)
         self.init_mpi()
         self.init_domain()
         self.init_fields()
@@ -131,6 +134,20 @@ class UnboundedFlowSimulator2D:
             self.flow_time_step = self.navier_stokes_timestep
         elif self.flow_type == "navier_stokes_with_forcing":
             self.flow_time_step = self.navier_stokes_with_forcing_timestep
+        if self.fused_step and self.flow_type in ["navier_stokes", "navier_stokes_with_forcing"]:
+            self.flow_time_step = self._fused_navier_stokes_timestep
+
+    def _fused_navier_stokes_timestep(self, dt, free_stream_velocity=(0.0, 0.0)):
+        """navier_stokes(_with_forcing)_timestep (:284-298) as one library call."""
+        lo = hi = None
+        if self.penalty_zone_width > 0:
+            lo, hi = self.penalise_field_towards_boundary.factor_tables
+        fs = darray(np.asarray(free_stream_velocity, dtype=self.real_t)) if self.with_free_stream_flow else None
+        forcing = as_ptr(self.eul_grid_forcing_field) if self.flow_type == "navier_stokes_with_forcing" else None
+        call("smi2d_flow_step_ns", self.ctx.handle, self.unbounded_poisson_solver.handle,
+             as_ptr(self.vorticity_field), as_ptr(self.velocity_field), as_ptr(self.stream_func_field),
+             as_ptr(self.buffer_scalar_field), forcing, float(dt), float(self.kinematic_viscosity), float(self.dx),
+             int(self.penalty_zone_width), lo, hi, fs)
 
     def update_simulator_time(self, dt):
         self.time += dt

@@ -88,13 +88,15 @@ def test_2d_poisson(smi, shape, real_t):
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
 @pytest.mark.parametrize("flow_type,free_stream", [("passive_scalar", False), ("navier_stokes", True),
                                                    ("navier_stokes_with_forcing", True)])
-def test_2d_flow_steps(smi, flow_type, free_stream, real_t):
+@pytest.mark.parametrize("fused_step", [True, False])
+def test_2d_flow_steps(smi, flow_type, free_stream, real_t, fused_step):
+    """fused_step: one library call per step (smi2d_flow_step_ns) or the operator-by-operator sequence."""
     from sopht_mpi_amd.simulator import UnboundedFlowSimulator2D
 
     rng = np.random.default_rng(6)
     kw = dict(grid_size=(32, 48), x_range=1.0, kinematic_viscosity=5e-3, flow_type=flow_type, real_t=real_t,
               with_free_stream_flow=free_stream)
-    gpu, cpu = UnboundedFlowSimulator2D(**kw), OracleSim2D(**kw)
+    gpu, cpu = UnboundedFlowSimulator2D(fused_step=fused_step, **kw), OracleSim2D(**kw)
     x, y = cpu.position_field
     w0 = (np.exp(-((x - 0.45) ** 2 + (y - 0.3) ** 2) / (2 * 0.06**2))
           - 0.5 * np.exp(-((x - 0.6) ** 2 + (y - 0.35) ** 2) / (2 * 0.05**2))).astype(real_t)
