@@ -11,8 +11,9 @@ Two implementations:
     The worker processes never import torch: a second HIP runtime in the process (torch
     bundles its own) is exactly what this library must not share an address space with.
 """
+import io
+import json
 import os
-import pickle
 import socket
 import struct
 import threading
@@ -42,6 +43,31 @@ class SingleWorld:
     def sendrecv(self, send_arrays, recv_arrays):
         """send_arrays / recv_arrays: dict peer -> numpy array.  Nothing to do on one rank."""
         assert not send_arrays and not recv_arrays
+
+
+def encode_object(obj):
+    """Wire form of what the ranks broadcast to each other: None, a numpy array (npy format,
+    no pickled object arrays) or plain data (JSON).  Nothing received is ever unpickled."""
+    if obj is None:
+        return b"N"
+    if isinstance(obj, np.ndarray):
+        buf = io.BytesIO()
+        np.save(buf, obj, allow_pickle=False)
+        return b"A" + buf.getvalue()
+    if isinstance(obj, np.generic):
+        obj = obj.item()
+    return b"J" + json.dumps(obj).encode()
+
+
+def decode_object(data):
+    tag, body = data[:1], data[1:]
+    if tag == b"N":
+        return None
+    if tag == b"A":
+        return np.load(io.BytesIO(body), allow_pickle=False)
+    if tag == b"J":
+        return json.loads(body.decode())
+    raise ValueError("unknown object tag in broadcast")
 
 
 def _recv_exact(sock, n):
@@ -126,7 +152,7 @@ class SocketWorld:
         return bytes(self._recv(root))
 
     def bcast_object(self, obj, root=0):
-        return pickle.loads(self.bcast_bytes(pickle.dumps(obj) if self.rank == root else b"", root))
+        return decode_object(self.bcast_bytes(encode_object(obj) if self.rank == root else b"", root))
 
     def allreduce(self, value, op="sum"):
         fn = {"sum": sum, "min": min, "max": max}[op]

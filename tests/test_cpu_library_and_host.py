@@ -127,3 +127,20 @@ def test_forcing_grid_api(smi):
     assert f[:, 0].tolist() == [-2.0, 0.0, -2.0]
     # torque about the centre (0.5, 0.5, 0.5): -(r x F) summed
     assert t[:, 0] == pytest.approx([0.0, -(-(-0.1) * 0.0 - 0.1 * 2.0) * -1, 0.0]) or True
+
+
+def test_world_objects_travel_without_pickle():
+    """What ranks broadcast to each other is encoded as npy / JSON; object arrays are refused."""
+    import numpy as np
+    import pytest
+    from sopht_mpi_amd.world import decode_object, encode_object
+
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert np.array_equal(decode_object(encode_object(a)), a)
+    assert decode_object(encode_object(None)) is None
+    assert decode_object(encode_object({"k": [1, 2.5, "x"]})) == {"k": [1, 2.5, "x"]}
+    assert decode_object(encode_object(np.float64(1.5))) == 1.5
+    with pytest.raises(ValueError):
+        encode_object(np.array([object()], dtype=object))
+    with pytest.raises(ValueError):
+        decode_object(b"P" + b"\x80\x04N.")
