@@ -30,3 +30,22 @@ def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     for r in range(nranks):
         assert f"rank {r} ok" in out.stdout
+
+
+def test_rccl_communicator_initialises(smi):
+    """The RCCL transport cannot run across ranks on a one-GPU box (RCCL refuses two ranks on one
+    device); what can be checked here is that the library's communicator set-up path (unique id,
+    ncclCommInitRank, destruction with the context) works against the RCCL of this image."""
+    import ctypes as C
+
+    from sopht_mpi_amd._lib import call, lib
+
+    h = C.c_void_p()
+    call("smi_ctx_create", C.byref(h), 0, 0, 16, 16, 16, 2, 0, 1)
+    buf = C.create_string_buffer(128)
+    call("smi_comm_unique_id", buf)
+    call("smi_comm_init", h, buf)
+    out = (C.c_double * 1)(3.5)
+    call("smi_allreduce_f64", h, out, 1, 0)  # one rank: the value comes back unchanged
+    assert out[0] == 3.5
+    assert lib.smi_ctx_destroy(h) == 0
