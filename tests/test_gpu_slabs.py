@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (2, "navier_stokes_with_forcing", "fused", "32x16x32"),
     (4, "navier_stokes_with_forcing", "fused", "32x16x32"),
     (4, "navier_stokes", "fused", "192x16x32"),   # a 192-point (radix 8 x 3 x 8) transform across the slabs
+    (8, "navier_stokes_with_forcing", "fused", "64x32x64"),  # the largest rank count of the scaling runs: 9 of 65 columns per rank
 ])
 def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
     env = dict(os.environ)
