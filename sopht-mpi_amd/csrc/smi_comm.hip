@@ -172,25 +172,51 @@ extern "C" int smi_planes_h2d(smi_ctx* c, void* field, int ncomp, int z0, int np
   return 0;
 }
 
-// zero the g ghost layers on all six sides (MPIGhostSumCommunicator3D.clear_ghost_cells)
+// zero the g ghost layers on all six sides (MPIGhostSumCommunicator3D.clear_ghost_cells).
+// Only the shell is visited: the z ghost planes are contiguous runs, and on an interior plane
+// the ghosts are the first and last g rows plus 2g cells of every other row.
 template <typename T>
-__global__ void __launch_bounds__(256) k_clear_ghosts(T* __restrict__ f, int pz, int py, int px, int g,
-                                                      long long plane, long long vol, int ncomp) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= vol * ncomp) return;
-  long long r = i % vol;
-  int z = (int)(r / plane);
-  long long rr = r - (long long)z * plane;
-  int y = (int)(rr / px), x = (int)(rr - (long long)y * px);
-  if (x < g || x >= px - g || y < g || y >= py - g || z < g || z >= pz - g) f[i] = T(0);
+__global__ void __launch_bounds__(256) k_clear_ghost_planes(T* __restrict__ f, int pz, int g, long long plane,
+                                                            long long vol) {
+  // grid.y = component * 2 + (0: low planes, 1: high planes)
+  T* base = f + (long long)(blockIdx.y >> 1) * vol + ((blockIdx.y & 1) ? (long long)(pz - g) * plane : 0);
+  const long long n = (long long)g * plane;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    base[i] = T(0);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_clear_ghost_rims(T* __restrict__ f, int pz, int py, int px, int g,
+                                                          long long plane, long long vol) {
+  // grid.y = interior plane, grid.z = component
+  T* p = f + (long long)blockIdx.z * vol + (long long)(g + blockIdx.y) * plane;
+  const int rows = g * px, rim = 2 * rows + (py - 2 * g) * 2 * g;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rim; i += gridDim.x * blockDim.x) {
+    long long off;
+    if (i < rows) {
+      off = i;
+    } else if (i < 2 * rows) {
+      off = (long long)(py - g) * px + (i - rows);
+    } else {
+      const int r = i - 2 * rows, y = g + r / (2 * g), s = r % (2 * g);
+      off = (long long)y * px + (s < g ? s : px - 2 * g + s);
+    }
+    p[off] = T(0);
+  }
 }
 
 extern "C" int smi_clear_ghost_cells(smi_ctx* c, void* field, int ncomp) {
   SMI_REQUIRE(c && field && ncomp >= 1, "smi_clear_ghost_cells: bad argument");
-  long long n = (long long)c->vol * ncomp;
+  if (c->g == 0) return 0;
+  const long long n = (long long)c->g * c->plane;
+  const int bp = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  const int rim = 2 * c->g * c->px + (c->py - 2 * c->g) * 2 * c->g;
+  const int nz_int = c->pz - 2 * c->g;
   SMI_DISPATCH(c, {
-    k_clear_ghosts<T><<<(int)((n + 255) / 256), 256, 0, c->stream>>>((T*)field, c->pz, c->py, c->px, c->g,
-                                                                    (long long)c->plane, (long long)c->vol, ncomp);
+    k_clear_ghost_planes<T><<<dim3(bp, 2 * ncomp), 256, 0, c->stream>>>((T*)field, c->pz, c->g, (long long)c->plane,
+                                                                       (long long)c->vol);
+    if (nz_int > 0)
+      k_clear_ghost_rims<T><<<dim3((rim + 255) / 256, nz_int, ncomp), 256, 0, c->stream>>>(
+          (T*)field, c->pz, c->py, c->px, c->g, (long long)c->plane, (long long)c->vol);
   });
   SMI_LAUNCH_CHECK();
   return 0;

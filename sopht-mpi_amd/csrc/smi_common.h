@@ -112,5 +112,6 @@ int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* fiel
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
+int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add);
 // true when this context has neighbours to exchange with
 static inline bool smi_multi_rank(const smi_ctx* c) { return c->nranks > 1; }

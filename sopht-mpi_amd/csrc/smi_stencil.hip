@@ -730,10 +730,15 @@ __global__ void __launch_bounds__(kTileThreads) k_diffuse_tiled(T* __restrict__ 
 // ---------------------------------------------------------------- curl, LDS tiled
 // k_curl MODE 0 on the 16-byte path, tiled and pipelined like k_diffuse_tiled: the three
 // components of the current plane are parked in LDS for the y+-1 / x+-1 reads, f_x and f_y of
-// the planes z-1 / z+1 stay in registers.
+// the planes z-1 / z+1 stay in registers.  `add` is a constant vector added to every cell of the
+// output, banded or not (the free stream that the flow step adds to the whole velocity array).
+template <typename T>
+struct Const3 {
+  T x, y, z;
+};
 template <typename T>
 __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out, const T* __restrict__ f, T pref,
-                                                            Geo G, int zchunk, TileShape S) {
+                                                            Geo G, int zchunk, TileShape S, Const3<T> add) {
   extern __shared__ char smi_tile_smem[];
   T* lds = reinterpret_cast<T*>(smi_tile_smem);
   const Blk B = xcd_block<true>();
@@ -748,11 +753,17 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
   const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
   const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
   const bool run = zs <= ze;  // uniform over the workgroup
-  const Pack<T, 4> zero = zero_pack<T, 4>();
+  Pack<T, 4> band[3];  // value of a cell outside the compute set
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    band[0].v[e] = add.x;
+    band[1].v[e] = add.y;
+    band[2].v[e] = add.z;
+  }
   for (int z = z0; z < (run ? zs : z1); ++z) {
     if (L.own) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) st<T, 4>(out + k * G.vol + z * G.plane + L.q, zero);
+      for (int k = 0; k < 3; ++k) st<T, 4>(out + k * G.vol + z * G.plane + L.q, band[k]);
     }
   }
   if (!run) return;
@@ -791,9 +802,9 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
       const T cx = pref * (fz_yp.v[e] - fz_ym.v[e] - nxt.y.v[e] + prev.y.v[e]);
       const T cy = pref * (nxt.x.v[e] - prev.x.v[e] - fzR + fzL);
       const T cz = pref * (fyR - fyL - fx_yp.v[e] + fx_ym.v[e]);
-      rx.v[e] = core[e] ? cx : T(0);
-      ry.v[e] = core[e] ? cy : T(0);
-      rz.v[e] = core[e] ? cz : T(0);
+      rx.v[e] = (core[e] ? cx : T(0)) + add.x;
+      ry.v[e] = (core[e] ? cy : T(0)) + add.y;
+      rz.v[e] = (core[e] ? cz : T(0)) + add.z;
     }
     if (L.own) {
       const long long zo = z * G.plane + L.q;
@@ -816,7 +827,7 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
   for (int z = ze + 1; z < z1; ++z) {
     if (L.own) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) st<T, 4>(out + k * G.vol + z * G.plane + L.q, zero);
+      for (int k = 0; k < 3; ++k) st<T, 4>(out + k * G.vol + z * G.plane + L.q, band[k]);
     }
   }
 }
@@ -1156,17 +1167,24 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
   return 0;
 }
 
+// `add` (MODE 0 only, may be null): constant vector added to the whole output array, i.e. the
+// add_fixed_val that follows the curl in compute_flow_velocity (flow_simulators_mpi_3d.py:382-393),
+// folded into the store of the tiled kernel; the other paths run it as a second pass.
 template <int MODE>
-static int run_curl(smi_ctx* c, void* out, void* f, double prefactor) {
+static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const double* add = nullptr) {
   SMI_REQUIRE(out != f, "curl operators: output and input must not alias");
   if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
   Geo G = make_geo(c);
-  SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
-  SMI_DISPATCH(c, {
+  bool added = add == nullptr;
+  {
+    SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
+    SMI_DISPATCH(c, {
     if (MODE == 0 && vec_ok<T>(c, out, f)) {
       const TiledLaunch t = tiled_launch<T>(c, 3, 1);
       SMI_CHECK(allow_lds(k_curl_tiled<T>));
-      k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S);
+      const Const3<T> a = add ? Const3<T>{(T)add[0], (T)add[1], (T)add[2]} : Const3<T>{T(0), T(0), T(0)};
+      k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S, a);
+      added = true;
     } else if (vec_ok<T>(c, out, f)) {
       LaunchShape s = plan<4>(c, 1);
       k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
@@ -1174,9 +1192,16 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor) {
       LaunchShape s = plan<1>(c, 1);
       k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
     }
-  });
-  SMI_LAUNCH_CHECK();
+    });
+    SMI_LAUNCH_CHECK();
+  }
+  if (!added) SMI_CHECK(smi_add_fixed_val(c, out, out, 3, add));
   return 0;
+}
+
+// u = prefactor * curl(field) + add on the whole array (add may be null)
+int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add) {
+  return run_curl<0>(c, curl, field, prefactor, add);
 }
 
 extern "C" int smi_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vorticity, void* forcing,

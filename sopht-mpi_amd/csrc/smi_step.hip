@@ -62,8 +62,8 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
   }
   SMI_CHECK(smi_penalise_boundary(c, vorticity, 3, penalty_width, fac_lo, fac_hi));
   SMI_CHECK(smi_poisson_vector_solve(p, stream_func, vorticity));
-  SMI_CHECK(smi_curl(c, velocity, stream_func, pref_vel));
-  if (free_stream) SMI_CHECK(smi_add_fixed_val(c, velocity, velocity, 3, free_stream));
+  // curl and the free stream in one pass over the velocity array
+  SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream));
   if (forcing) {
     double z3[3] = {0, 0, 0};
     SMI_CHECK(smi_set_fixed_val(c, forcing, 3, z3));
