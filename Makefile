@@ -4,7 +4,7 @@ ARCH    ?= gfx950
 CSRC    := sopht-mpi_amd/csrc
 OUT     := sopht-mpi_amd/sopht_mpi_amd/lib/libsophtmi.so
 SRCS    := $(CSRC)/smi_core.hip $(CSRC)/smi_stencil.hip $(CSRC)/smi_poisson.hip $(CSRC)/smi_fft.hip \
-           $(CSRC)/smi_ib.hip $(CSRC)/smi_comm.hip $(CSRC)/smi_step.hip $(CSRC)/smi_2d.hip
+           $(CSRC)/smi_ib.hip $(CSRC)/smi_comm.hip $(CSRC)/smi_step.hip $(CSRC)/smi_2d.hip $(CSRC)/smi_fftapi.hip
 OBJS    := $(SRCS:.hip=.o)
 # packed-fp32 VALU forms are switched off on purpose ("compile flags")
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) \

@@ -157,6 +157,10 @@ int smi_laplacian_filter(smi_ctx* ctx, void* field, int ncomp, void* filter_flux
  * advection_timestep_mpi_3d.py:12-95 (+ advection_flux_mpi_3d.py:8-195) */
 int smi_advection_timestep_eno3(smi_ctx* ctx, void* field, void* flux, void* velocity,
                                 double dt_by_dx, int ncomp);
+/* gen_advection_flux_conservative_eno3_pyst_mpi_kernel_3d (stencil_ops_3d/advection_flux_mpi_3d.py:8-195):
+ * flux = inv_dx * (conservative upwind flux divergence) on the cells the wrapper's boxes cover; the other
+ * cells of flux keep their values (the wrapper never writes them). */
+int smi_advection_flux_eno3(smi_ctx* ctx, void* flux, void* field, void* velocity, double inv_dx);
 
 /* ---- reductions (flow_simulators_mpi_3d.py:426-476); LOCAL values, the host
  *      launcher combines ranks (allreduce MIN / MAX / SUM) -------------------------- */
@@ -177,6 +181,21 @@ int smi_poisson_vector_solve(smi_poisson* p, void* solution, const void* rhs);
 /* debug / test: download the compact Green's-function spectrum */
 size_t smi_poisson_greens_size(smi_poisson* p);
 int smi_poisson_greens_download(smi_poisson* p, void* host);
+
+/* ---- stand-alone FFT plans and doubled-domain copies (single rank) --------------------------
+ * FFTMPI3D (poisson_solver_3d/fft_mpi_3d.py:5-48) / FFTMPI2D (poisson_solver_2d/fft_mpi_2d.py:5-45):
+ * real (nz, ny, nx) <-> complex (nz, ny, nx/2 + 1), contiguous, no ghosts; nz = 1 makes a 2D plan.
+ * forward is unnormalised, backward divides by nz*ny*nx and leaves its input intact. */
+typedef struct smi_fft smi_fft;
+int smi_fft_create(smi_fft** out, smi_ctx* ctx, int nz, int ny, int nx);
+int smi_fft_destroy(smi_fft* f);
+int smi_fft_forward(smi_fft* f, const void* field, void* fourier_field);
+int smi_fft_backward(smi_fft* f, const void* fourier_field, void* inv_fourier_field);
+/* MPIDomainDoublingCommunicator3D.copy_to_doubled_domain / copy_from_doubled_domain
+ * (UnboundedPoissonSolverMPI3D.py:314-382; 2D: UnboundedPoissonSolverMPI2D.py:273-352): interior of
+ * the ghosted local field <-> first octant (quadrant) of the contiguous doubled array. */
+int smi_copy_to_doubled_domain(smi_ctx* ctx, const void* local_field, void* local_doubled_field);
+int smi_copy_from_doubled_domain(smi_ctx* ctx, const void* local_doubled_field, void* local_field);
 
 /* ---- immersed boundary ------------------------------------------------------------
  * EulerianLagrangianGridCommunicatorMPI3D.py:116-589 and VirtualBoundaryForcingMPI.py:278-459.
@@ -233,6 +252,8 @@ int smi2d_diffusion_timestep(smi_ctx* ctx, void* field, void* flux, double nu_dt
 /* stencil_ops_2d/advection_timestep_mpi_2d.py, advection_flux_mpi_2d.py (kernel support 2) */
 int smi2d_advection_timestep_eno3(smi_ctx* ctx, void* field, void* flux, const void* velocity,
                                   double dt_by_dx);
+/* stencil_ops_2d/advection_flux_mpi_2d.py: the flux alone (cells outside the wrapper's boxes keep their values) */
+int smi2d_advection_flux_eno3(smi_ctx* ctx, void* flux, const void* field, const void* velocity, double inv_dx);
 /* stencil_ops_2d/outplane_field_curl_mpi_2d.py:30-139 (stream function -> velocity) */
 int smi2d_outplane_field_curl(smi_ctx* ctx, void* curl, const void* field, double prefactor);
 /* stencil_ops_2d/update_vorticity_from_velocity_forcing_mpi_2d.py */

@@ -78,14 +78,16 @@ __device__ __forceinline__ T upwind3_face2(const T* f, const T* v, long long str
 }
 
 // flux = c * (dF_x/dx + dF_y/dy) with the third-order upwind face flux, on U_2, 0 elsewhere
-template <typename T>
+// KEEP: cells outside U_2 keep their value (the stand-alone flux operator)
+template <typename T, bool KEEP = false>
 __global__ void __launch_bounds__(kB) k2_advection_flux(T* __restrict__ flux, const T* __restrict__ f,
                                                        const T* __restrict__ vel, T c, G2 G) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.n) return;
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   T val = T(0);
-  if (in_update_set(y, x, G, 2)) {
+  const bool in_u = in_update_set(y, x, G, 2);
+  if (in_u) {
     const T* fc = f + i;
     const T* vx = vel + i;
     const T* vy = vel + G.n + i;
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(kB) k2_advection_flux(T* __restrict__ flux, co
     const T dy = upwind3_face2(fc, vy, (long long)G.px) - upwind3_face2(fc - G.px, vy - G.px, (long long)G.px);
     val = c * (dx + dy);
   }
-  flux[i] = val;
+  if (!KEEP || in_u) flux[i] = val;
 }
 
 template <typename T>
@@ -253,6 +255,21 @@ extern "C" int smi2d_advection_timestep_eno3(smi_ctx* c, void* field, void* flux
     k2_advection_flux<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (const T*)velocity,
                                                             (T)(-dt_by_dx), G);
     k2_sum<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)field, (const T*)field, (const T*)flux, G.n);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// gen_advection_flux_conservative_eno3_pyst_mpi_kernel_2d (advection_flux_mpi_2d.py): the flux alone
+extern "C" int smi2d_advection_flux_eno3(smi_ctx* c, void* flux, const void* field, const void* velocity,
+                                         double inv_dx) {
+  SMI_CHECK(require_2d(c, "smi2d_advection_flux_eno3"));
+  SMI_REQUIRE(field && flux && velocity && flux != field, "smi2d_advection_flux_eno3: bad argument");
+  SMI_REQUIRE(c->g >= 2, "smi2d_advection_flux_eno3: kernel support 2 needs ghost_size >= 2 (got %d)", c->g);
+  G2 G = geo2(c);
+  SMI_DISPATCH(c, {
+    k2_advection_flux<T, true><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (const T*)velocity,
+                                                                  (T)inv_dx, G);
   });
   SMI_LAUNCH_CHECK();
   return 0;

@@ -865,7 +865,8 @@ __device__ __forceinline__ T upwind3_face(const T* f, const T* v, long long stri
   return vf * (vf > T(0) ? left : right);
 }
 
-template <typename T>
+// KEEP: cells outside W keep their value (the stand-alone flux operator writes W only).
+template <typename T, bool KEEP = false>
 __global__ void __launch_bounds__(kBlock) k_advection_flux(T* __restrict__ flux, const T* __restrict__ f,
                                                           const T* __restrict__ vel, T c, Geo G) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -890,7 +891,7 @@ __global__ void __launch_bounds__(kBlock) k_advection_flux(T* __restrict__ flux,
     const T dz = upwind3_face(fc, vz, G.plane) - upwind3_face(fc - G.plane, vz - G.plane, G.plane);
     val = c * (dx + dy + dz);
   }
-  flux[i] = val;
+  if (!KEEP || in_w) flux[i] = val;
 }
 
 // ---------------------------------------------------------------- divergence (diagnostic)
@@ -1392,6 +1393,26 @@ extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* fi
       }
     }
   });
+  return 0;
+}
+
+// gen_advection_flux_conservative_eno3_pyst_mpi_kernel_3d (advection_flux_mpi_3d.py:8-195): the flux
+// alone, written on the cells the wrapper's seven boxes cover; the rest of `flux` is left as it is.
+extern "C" int smi_advection_flux_eno3(smi_ctx* c, void* flux, void* field, void* velocity, double inv_dx) {
+  SMI_REQUIRE(c && field && flux && velocity, "smi_advection_flux_eno3: bad argument");
+  SMI_REQUIRE(flux != field && flux != velocity, "smi_advection_flux_eno3: flux must not alias its inputs");
+  SMI_REQUIRE(c->g >= 2, "smi_advection_flux_eno3: kernel support 2 needs ghost_size >= 2 (got %d)", c->g);
+  if (smi_multi_rank(c)) {
+    SMI_CHECK(smi_halo_exchange_impl(c, field, 1));
+    SMI_CHECK(smi_halo_exchange_impl(c, velocity, 3));
+  }
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, PROF_ADVECTION, 5.0 * smi_S(c));
+  SMI_DISPATCH(c, {
+    k_advection_flux<T, true><<<blocks_for(G.vol), kBlock, 0, c->stream>>>((T*)flux, (const T*)field,
+                                                                          (const T*)velocity, (T)inv_dx, G);
+  });
+  SMI_LAUNCH_CHECK();
   return 0;
 }
 

@@ -69,6 +69,7 @@ SIGNATURES = {
     "smi_penalise_boundary": [_p, _p, _i, _i, _dp, _dp],
     "smi_laplacian_filter": [_p, _p, _i, _p, _p, _i, _i],
     "smi_advection_timestep_eno3": [_p, _p, _p, _p, _d, _i],
+    "smi_advection_flux_eno3": [_p, _p, _p, _p, _d],
     "smi_rotational_advection_update": [_p, _p, _p, _p, _d],
     "smi_reduce_max_abs_sum": [_p, _p, _dp],
     "smi_reduce_max": [_p, _p, _i, _dp],
@@ -78,6 +79,12 @@ SIGNATURES = {
     "smi_poisson_solve": [_p, _p, _p],
     "smi_poisson_vector_solve": [_p, _p, _p],
     "smi_poisson_greens_download": [_p, _p],
+    "smi_fft_create": [_pp, _p, _i, _i, _i],
+    "smi_fft_destroy": [_p],
+    "smi_fft_forward": [_p, _p, _p],
+    "smi_fft_backward": [_p, _p, _p],
+    "smi_copy_to_doubled_domain": [_p, _p, _p],
+    "smi_copy_from_doubled_domain": [_p, _p, _p],
     "smi_ib_support": [_p, _p, _p, _p, _i64, _d, _d, _i64p],
     "smi_ib_weights": [_p, _p, _p, _i64, _d, _i],
     "smi_ib_interpolate": [_p, _p, _p, _p, _p, _i64, _i, _d],
@@ -93,6 +100,7 @@ SIGNATURES = {
     "smi2d_diffusion_flux": [_p, _p, _p, _d],
     "smi2d_diffusion_timestep": [_p, _p, _p, _d],
     "smi2d_advection_timestep_eno3": [_p, _p, _p, _p, _d],
+    "smi2d_advection_flux_eno3": [_p, _p, _p, _p, _d],
     "smi2d_outplane_field_curl": [_p, _p, _p, _d],
     "smi2d_update_vorticity_from_velocity_forcing": [_p, _p, _p, _d],
     "smi2d_penalise_boundary": [_p, _p, _i, _dp, _dp],

@@ -71,6 +71,18 @@ def gen_diffusion_timestep_euler_forward_pyst_mpi_kernel_3d(real_t, mpi_construc
 
 
 # ------------------------------------------------------------------ advection (ENO3)
+def gen_advection_flux_conservative_eno3_pyst_mpi_kernel_3d(real_t, mpi_construct, ghost_exchange_communicator):
+    """stencil_ops_3d/advection_flux_mpi_3d.py:8-195 (scalar fields; kernel support 2)."""
+    ctx = ghost_exchange_communicator.ctx
+
+    def advection_flux_conservative_eno3_pyst_mpi_kernel_3d(advection_flux, field, velocity, inv_dx):
+        call("smi_advection_flux_eno3", ctx.handle, as_ptr(advection_flux), as_ptr(field), as_ptr(velocity),
+             float(inv_dx))
+
+    return _support(gen_advection_flux_conservative_eno3_pyst_mpi_kernel_3d,
+                    advection_flux_conservative_eno3_pyst_mpi_kernel_3d, 2, ghost_exchange_communicator)
+
+
 def gen_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d(
     real_t, mpi_construct, ghost_exchange_communicator, field_type="scalar"
 ):
@@ -284,5 +296,104 @@ class UnboundedPoissonSolverMPI3D:
             pass
 
 
-__all__ = [n for n in dir() if n.startswith("gen_")] + ["UnboundedPoissonSolverMPI3D", "penalty_factor_tables"]
+class _DeviceFFT:
+    """Shared part of FFTMPI3D / FFTMPI2D: a hipFFT real-to-complex plan pair on the rank's GPU with
+    the reference's buffers and normalisation (forward unnormalised, backward normalised)."""
+
+    def _setup(self, shape, mpi_construct, real_t):
+        if mpi_construct.size > 1:
+            raise RuntimeError(
+                "the stand-alone FFT runs on one rank; across slabs the transform is part of "
+                "UnboundedPoissonSolverMPI3D (pruned back end)"
+            )
+        self.real_dtype = np.dtype(real_t).type
+        if self.real_dtype not in (np.float32, np.float64):
+            raise ValueError(f"unsupported real type {real_t}")
+        self.complex_dtype = np.complex64 if self.real_dtype == np.float32 else np.complex128
+        if np.dtype(mpi_construct.real_t) != np.dtype(real_t):
+            raise ValueError("real_t differs from the precision of mpi_construct")
+        self.ctx = mpi_construct.device_context(2)
+        self.shape = tuple(int(n) for n in shape)
+        self.fourier_shape = self.shape[:-1] + (self.shape[-1] // 2 + 1,)
+        self.field_buffer = self.ctx.zeros(self.shape, self.real_dtype)
+        self.fourier_field_buffer = self.ctx.zeros(self.fourier_shape, self.complex_dtype)
+        nz, ny, nx = ((1,) + self.shape)[-3:]
+        h = C.c_void_p()
+        call("smi_fft_create", C.byref(h), self.ctx.handle, nz, ny, nx)
+        self.handle = h
+
+    def _check(self, arr, shape, dtype, what):
+        if tuple(arr.shape) != shape or np.dtype(arr.dtype) != np.dtype(dtype):
+            raise ValueError(f"{what} must be a {np.dtype(dtype).name} array of shape {shape}")
+
+    def forward(self, field, fourier_field):
+        """Real-to-complex transform, unnormalised (fft_mpi_3d.py:34-39)."""
+        self._check(field, self.shape, self.real_dtype, "field")
+        self._check(fourier_field, self.fourier_shape, self.complex_dtype, "fourier_field")
+        call("smi_fft_forward", self.handle, as_ptr(field), as_ptr(fourier_field))
+
+    def backward(self, fourier_field, inv_fourier_field):
+        """Complex-to-real transform, normalised (fft_mpi_3d.py:41-48); the input is preserved."""
+        self._check(fourier_field, self.fourier_shape, self.complex_dtype, "fourier_field")
+        self._check(inv_fourier_field, self.shape, self.real_dtype, "inv_fourier_field")
+        call("smi_fft_backward", self.handle, as_ptr(fourier_field), as_ptr(inv_fourier_field))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.ctx.handle:
+                _lib.lib.smi_fft_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class FFTMPI3D(_DeviceFFT):
+    """poisson_solver_3d/fft_mpi_3d.py:5-48: real (z, y, x) <-> complex (z, y, x/2 + 1) DeviceFields."""
+
+    def __init__(self, grid_size_z, grid_size_y, grid_size_x, mpi_construct, real_t=np.float64):
+        self.grid_size_z, self.grid_size_y, self.grid_size_x = grid_size_z, grid_size_y, grid_size_x
+        self._setup((grid_size_z, grid_size_y, grid_size_x), mpi_construct, real_t)
+
+
+class _DomainDoubling:
+    def __init__(self, ghost_size, mpi_construct):
+        if ghost_size < 0 or not isinstance(ghost_size, (int, np.integer)):
+            raise ValueError(f"Ghost size {ghost_size} needs to be an integer >= 0 for field communication.")
+        if mpi_construct.size > 1:
+            raise RuntimeError(
+                "the doubled-domain copies run on one rank; across slabs the Poisson solver never builds "
+                "the doubled arrays"
+            )
+        if ghost_size < 1:
+            raise NotImplementedError("device contexts carry at least one ghost layer")
+        self.mpi_construct = mpi_construct
+        self.ghost_size = int(ghost_size)
+        self.field_grid_size = np.array(mpi_construct.local_grid_size)
+        self.field_doubled_grid_size = self.field_grid_size * 2
+        self.ctx = mpi_construct.device_context(self.ghost_size)
+
+    def _check(self, local_field, local_doubled_field):
+        g = self.ghost_size
+        if tuple(local_field.shape) != tuple(int(n) + 2 * g for n in self.field_grid_size):
+            raise ValueError("local_field must be the ghosted local array")
+        if tuple(local_doubled_field.shape) != tuple(int(n) for n in self.field_doubled_grid_size):
+            raise ValueError("local_doubled_field must have twice the local grid size and no ghosts")
+
+    def copy_to_doubled_domain(self, local_field, local_doubled_field):
+        """:314-347: interior of ``local_field`` -> first octant of ``local_doubled_field``."""
+        self._check(local_field, local_doubled_field)
+        call("smi_copy_to_doubled_domain", self.ctx.handle, as_ptr(local_field), as_ptr(local_doubled_field))
+
+    def copy_from_doubled_domain(self, local_doubled_field, local_field):
+        """:349-382."""
+        self._check(local_field, local_doubled_field)
+        call("smi_copy_from_doubled_domain", self.ctx.handle, as_ptr(local_doubled_field), as_ptr(local_field))
+
+
+class MPIDomainDoublingCommunicator3D(_DomainDoubling):
+    """poisson_solver_3d/UnboundedPoissonSolverMPI3D.py:190-382 on one rank."""
+
+
+__all__ = [n for n in dir() if n.startswith("gen_")] + [
+    "UnboundedPoissonSolverMPI3D", "FFTMPI3D", "MPIDomainDoublingCommunicator3D", "penalty_factor_tables"]
 from .ops_2d import *  # noqa: F401,F403,E402

@@ -38,6 +38,18 @@ def gen_diffusion_timestep_euler_forward_pyst_mpi_kernel_2d(real_t, mpi_construc
                     diffusion_timestep_euler_forward_pyst_mpi_kernel_2d, 1, ghost_exchange_communicator)
 
 
+def gen_advection_flux_conservative_eno3_pyst_mpi_kernel_2d(real_t, mpi_construct, ghost_exchange_communicator):
+    """stencil_ops_2d/advection_flux_mpi_2d.py (kernel support 2)."""
+    ctx = ghost_exchange_communicator.ctx
+
+    def advection_flux_conservative_eno3_pyst_mpi_kernel_2d(advection_flux, field, velocity, inv_dx):
+        call("smi2d_advection_flux_eno3", ctx.handle, as_ptr(advection_flux), as_ptr(field), as_ptr(velocity),
+             float(inv_dx))
+
+    return _support(gen_advection_flux_conservative_eno3_pyst_mpi_kernel_2d,
+                    advection_flux_conservative_eno3_pyst_mpi_kernel_2d, 2, ghost_exchange_communicator)
+
+
 def gen_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_2d(real_t, mpi_construct,
                                                                               ghost_exchange_communicator):
     """stencil_ops_2d/advection_timestep_mpi_2d.py (kernel support 2)."""
@@ -192,3 +204,22 @@ class UnboundedPoissonSolverMPI2D:
                 self.handle = None
         except Exception:
             pass
+
+
+def _late():
+    from . import _DeviceFFT, _DomainDoubling
+
+    class FFTMPI2D(_DeviceFFT):
+        """poisson_solver_2d/fft_mpi_2d.py:5-45: real (y, x) <-> complex (y, x/2 + 1) DeviceFields."""
+
+        def __init__(self, grid_size_y, grid_size_x, mpi_construct, real_t=np.float64):
+            self.grid_size_y, self.grid_size_x = grid_size_y, grid_size_x
+            self._setup((grid_size_y, grid_size_x), mpi_construct, real_t)
+
+    class MPIDomainDoublingCommunicator2D(_DomainDoubling):
+        """poisson_solver_2d/UnboundedPoissonSolverMPI2D.py:156-352 on one rank."""
+
+    return FFTMPI2D, MPIDomainDoublingCommunicator2D
+
+
+FFTMPI2D, MPIDomainDoublingCommunicator2D = _late()

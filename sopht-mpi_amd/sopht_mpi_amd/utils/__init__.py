@@ -314,3 +314,75 @@ class MPIGhostCommunicator2D:
 
     def exchange_finalise(self):
         pass
+
+
+class MPIFieldCommunicator2D:
+    """utils/mpi_utils_2d.py:424-568 on the single rank of the 2D path: the global host array
+    and the interior of the device field are the same cells."""
+
+    def __init__(self, ghost_size, mpi_construct, master_rank=0):
+        if ghost_size < 0 or not isinstance(ghost_size, (int, np.integer)):
+            raise ValueError(f"Ghost size {ghost_size} needs to be an integer >= 0 for field communication.")
+        self.mpi_construct = mpi_construct
+        self.ghost_size = int(ghost_size)
+        self.master_rank = master_rank
+        g = self.ghost_size
+        self.inner_idx = (slice(g, -g),) * 2 if g > 0 else (slice(None),) * 2
+
+    def scatter_global_scalar_field(self, local_field, global_field):
+        host = local_field.get()
+        host[self.inner_idx] = np.asarray(global_field)
+        local_field.set(host)
+
+    def gather_local_scalar_field(self, global_field, local_field):
+        global_field[...] = local_field.get()[self.inner_idx]
+
+    def scatter_global_vector_field(self, local_vector_field, global_vector_field):
+        for c in range(2):
+            self.scatter_global_scalar_field(local_vector_field[c], global_vector_field[c])
+
+    def gather_local_vector_field(self, global_vector_field, local_vector_field):
+        for c in range(2):
+            self.gather_local_scalar_field(global_vector_field[c], local_vector_field[c])
+
+
+class MPILagrangianFieldCommunicator2D:
+    """utils/mpi_utils_2d.py:571-712 on one rank: every node inside the domain belongs to rank 0;
+    a node outside raises (the reference logs and aborts the job, :628-640)."""
+
+    def __init__(self, eul_grid_dx, eul_grid_coord_shift, mpi_construct, master_rank=0, real_t=np.float64):
+        self.grid_dim = 2
+        self.mpi_construct = mpi_construct
+        self.master_rank = master_rank
+        self.rank = mpi_construct.rank
+        self.eul_subblock_dx = eul_grid_dx * mpi_construct.local_grid_size
+        self.eul_grid_coord_shift = eul_grid_coord_shift
+        self.real_t = real_t
+        self.rank_address = np.zeros(0, dtype=np.int32)
+        self.local_num_lag_nodes = 0
+
+    def _compute_lag_nodes_rank_address(self, global_lag_positions):
+        topo = self.mpi_construct.grid_topology
+        cy = ((global_lag_positions[1, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[0]).astype(np.int32)
+        cx = ((global_lag_positions[0, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[1]).astype(np.int32)
+        if np.any(cx >= topo[1]) or np.any(cy >= topo[0]) or np.any(cx < 0) or np.any(cy < 0):
+            logger.error("Lagrangian node is found outside of Eulerian domain!")
+            raise RuntimeError("Lagrangian node is found outside of Eulerian domain!")
+        return np.zeros(global_lag_positions.shape[-1], dtype=np.int32)
+
+    def map_lagrangian_nodes_based_on_position(self, global_lag_positions):
+        if global_lag_positions.shape[0] != self.grid_dim:
+            raise RuntimeError(f"global_lag_positions needs to be shape ({self.grid_dim}, ...)")
+        self.rank_address = self._compute_lag_nodes_rank_address(global_lag_positions)
+        self.local_nodes_idx = np.where(self.rank_address == self.rank)
+        self.local_num_lag_nodes = int(self.rank_address.shape[0])
+        self.slave_ranks_containing_lag_nodes = set()
+
+    def scatter_global_field(self, local_lag_field, global_lag_field):
+        local_lag_field[...] = np.asarray(global_lag_field)
+
+    def gather_local_field(self, global_lag_field, local_lag_field):
+        global_lag_field[...] = np.asarray(local_lag_field)
+
+
+__all__ += ["MPIConstruct2D", "MPIGhostCommunicator2D", "MPIFieldCommunicator2D", "MPILagrangianFieldCommunicator2D"]

@@ -113,6 +113,31 @@ def test_lagrangian_owner_map(smi):
         comm.map_lagrangian_nodes_based_on_position(bad)
 
 
+def test_2d_lagrangian_and_field_communicators(smi):
+    """utils/mpi_utils_2d.py:571-712 on the single rank of the 2D path: every node inside the domain is
+    local, scatter and gather are identities, a node outside raises."""
+    from sopht_mpi_amd.utils import MPIConstruct2D, MPIFieldCommunicator2D, MPILagrangianFieldCommunicator2D
+
+    n, dx = (8, 16), 1.0 / 16
+    c = MPIConstruct2D(*n, real_t=np.float64)
+    comm = MPILagrangianFieldCommunicator2D(dx, dx / 2, c)
+    pos = np.random.default_rng(1).uniform(0.1, 0.45, (2, 7))
+    comm.map_lagrangian_nodes_based_on_position(pos)
+    assert comm.local_num_lag_nodes == 7 and np.array_equal(comm.rank_address, np.zeros(7, dtype=np.int32))
+    local, back = np.zeros((2, 7)), np.zeros((2, 7))
+    comm.scatter_global_field(local, pos)
+    comm.gather_local_field(back, local)
+    assert np.array_equal(back, pos)
+    bad = pos.copy()
+    bad[1, 2] = 0.75  # y range is 0.5
+    with pytest.raises(RuntimeError):
+        comm.map_lagrangian_nodes_based_on_position(bad)
+    with pytest.raises(RuntimeError):
+        comm.map_lagrangian_nodes_based_on_position(np.zeros((3, 4)))
+    with pytest.raises(ValueError):
+        MPIFieldCommunicator2D(ghost_size=-1, mpi_construct=c)
+
+
 def test_forcing_grid_api(smi):
     from sopht_mpi_amd.simulator import EmptyForcingGrid, PrescribedForcingGrid
 
