@@ -304,6 +304,15 @@ constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per 
 #ifndef SMI_FFT_ZCOLS
 #define SMI_FFT_ZCOLS 0
 #endif
+// Row tiles one workgroup of the x kernels walks over (the twiddle set-up is then paid once for
+// all of them).  Measured at 512^3: two tiles take 7 % off x_inv and add 6 % to x_fwd; four or
+// more slow both down.
+#ifndef SMI_FFT_XT_FWD
+#define SMI_FFT_XT_FWD 1
+#endif
+#ifndef SMI_FFT_XT_INV
+#define SMI_FFT_XT_INV 2
+#endif
 #ifndef SMI_FFT_COLS_F32
 #define SMI_FFT_COLS_F32 16
 #endif
@@ -888,44 +897,47 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
-  const bool ok = y < G.ny && item;
-  const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
+  const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
-  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
   const Cx<T> w1 = tw4[1];  // exp(-i pi / 2L)
-  Cx<T> v[8], a0[8];
+  for (int it = 0; it < SMI_FFT_XT_FWD; ++it) {
+    const int y = (blockIdx.x * SMI_FFT_XT_FWD + it) * TS + t;
+    const bool ok = y < G.ny && item;
+    const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
+    const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
+    Cx<T> v[8], a0[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) a0[m] = ok ? load_pair(row + 2 * (u + m * L8), F.vec2) : Cx<T>{0, 0};
+    for (int m = 0; m < 8; ++m) a0[m] = ok ? load_pair(row + 2 * (u + m * L8), F.vec2) : Cx<T>{0, 0};
 #pragma unroll
-  for (int parity = 0; parity < 2; ++parity) {
+    for (int parity = 0; parity < 2; ++parity) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
-    fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
-    Cx<T>* z = sel.next();
-    if (item) {
+      for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
+      fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
+      Cx<T>* z = sel.next();
+      if (item) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) z[Lay::idx(u + m * L8, t)] = v[m];
-    }
-    __syncthreads();
-    if (ok) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int k = u + m * L8;
-        const int kp = parity ? L - 1 - k : (k ? L - k : 0);
-        const Cx<T> a = v[m], b = conj(z[Lay::idx(kp, t)]);
-        Cx<T> w = mul_c16(wu, m);  // exp(-i pi k / L)
-        if (parity) w = w * w1;
-        const Cx<T> sm = a + b, d = w * (a - b);
-        const Cx<T> X{(T)0.5 * (sm.x + d.y), (T)0.5 * (sm.y - d.x)};  // s/2 - (i/2) d
-        stream_store(&out[colA(G, rowbase, rank_stride, parity ? L + 1 + k : k)], X);
+        for (int m = 0; m < 8; ++m) z[Lay::idx(u + m * L8, t)] = v[m];
       }
-      if (parity == 0 && u == 0) {
-        // kx = 2L (j = L): X = Re Z[0] - Im Z[0]
-        out[colA(G, rowbase, rank_stride, L)] = Cx<T>{v[0].x - v[0].y, T(0)};
+      __syncthreads();
+      if (ok) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int k = u + m * L8;
+          const int kp = parity ? L - 1 - k : (k ? L - k : 0);
+          const Cx<T> a = v[m], b = conj(z[Lay::idx(kp, t)]);
+          Cx<T> w = mul_c16(wu, m);  // exp(-i pi k / L)
+          if (parity) w = w * w1;
+          const Cx<T> sm = a + b, d = w * (a - b);
+          const Cx<T> X{(T)0.5 * (sm.x + d.y), (T)0.5 * (sm.y - d.x)};  // s/2 - (i/2) d
+          stream_store(&out[colA(G, rowbase, rank_stride, parity ? L + 1 + k : k)], X);
+        }
+        if (parity == 0 && u == 0) {
+          // kx = 2L (j = L): X = Re Z[0] - Im Z[0]
+          out[colA(G, rowbase, rank_stride, L)] = Cx<T>{v[0].x - v[0].y, T(0)};
+        }
       }
+      sel.after_read();
     }
-    sel.after_read();
   }
 }
 
@@ -938,39 +950,42 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  const int c = G.c0 + blockIdx.z, zl = blockIdx.y, y = blockIdx.x * TS + t;
-  const bool ok = y < G.ny && item;
-  T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
+  const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
-  const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
   const Cx<T> w1 = tw4[1];
-  Cx<T> v[8], res[8];
+  for (int it = 0; it < SMI_FFT_XT_INV; ++it) {
+    const int y = (blockIdx.x * SMI_FFT_XT_INV + it) * TS + t;
+    const bool ok = y < G.ny && item;
+    T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
+    const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
+    Cx<T> v[8], res[8];
 #pragma unroll
-  for (int parity = 0; parity < 2; ++parity) {
-    Cx<T> xa[8], xb[8];
+    for (int parity = 0; parity < 2; ++parity) {
+      Cx<T> xa[8], xb[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int k = u + m * L8;
-      const int ja = parity ? L + 1 + k : k;
-      const int jb = parity ? 2 * L - k : L - k;  // mirror column M - kx in the same parity block
-      xa[m] = ok ? in[colA(G, rowbase, rank_stride, ja)] : Cx<T>{0, 0};
-      xb[m] = ok ? in[colA(G, rowbase, rank_stride, jb)] : Cx<T>{0, 0};
-    }
+      for (int m = 0; m < 8; ++m) {
+        const int k = u + m * L8;
+        const int ja = parity ? L + 1 + k : k;
+        const int jb = parity ? 2 * L - k : L - k;  // mirror column M - kx in the same parity block
+        xa[m] = ok ? in[colA(G, rowbase, rank_stride, ja)] : Cx<T>{0, 0};
+        xb[m] = ok ? in[colA(G, rowbase, rank_stride, jb)] : Cx<T>{0, 0};
+      }
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      Cx<T> w = mul_c16(wu, m);
-      if (parity) w = w * w1;
-      const Cx<T> sm = xa[m] + conj(xb[m]), d = conj(w) * (xa[m] - conj(xb[m]));
-      v[m] = Cx<T>{(T)0.5 * (sm.x - d.y), (T)0.5 * (sm.y + d.x)};  // s/2 + (i/2) d
-    }
-    fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
-    if (parity == 0) {
+      for (int m = 0; m < 8; ++m) {
+        Cx<T> w = mul_c16(wu, m);
+        if (parity) w = w * w1;
+        const Cx<T> sm = xa[m] + conj(xb[m]), d = conj(w) * (xa[m] - conj(xb[m]));
+        v[m] = Cx<T>{(T)0.5 * (sm.x - d.y), (T)0.5 * (sm.y + d.x)};  // s/2 + (i/2) d
+      }
+      fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
+      if (parity == 0) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) res[m] = v[m];
-    } else if (ok) {
+        for (int m = 0; m < 8; ++m) res[m] = v[m];
+      } else if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m)
-        store_pair(row + 2 * (u + m * L8), res[m] + conj(mul_c16(wu, m)) * v[m], F.vec2);
+        for (int m = 0; m < 8; ++m)
+          store_pair(row + 2 * (u + m * L8), res[m] + conj(mul_c16(wu, m)) * v[m], F.vec2);
+      }
     }
   }
 }
@@ -1201,7 +1216,8 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, voi
   // rows start g reals into a padded row: pairs are aligned when g and the row pitch are even
   const int vec2 = (c->g % 2 == 0) && (c->px % 2 == 0) && ((uintptr_t)field % (2 * sizeof(T)) == 0);
   FieldGeo F{c->g, c->px, vec2, (long long)c->plane, (long long)c->vol};
-  dim3 grid((G.ny + TS - 1) / TS, G.nzl, nc);
+  const int xt = fwd ? SMI_FFT_XT_FWD : SMI_FFT_XT_INV;
+  dim3 grid((G.ny + TS * xt - 1) / (TS * xt), G.nzl, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[0];
   if (fwd) {
     SMI_CHECK(set_lds((const void*)k_fft_x_fwd<T, LG>, lds_bytes));
