@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 ALG_BYTES_PER_POINT_STEP = 1692.0
 MIN_BYTES_PER_POINT_STEP = 660.0
 IMPL_BYTES_PER_POINT_STEP = 408.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_counters_512cubed_v6.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_counters_512cubed_v7.json")
 
 
 def synthetic_vorticity(position_field, real_t, seed=0, nblobs=8, sigma=0.05):

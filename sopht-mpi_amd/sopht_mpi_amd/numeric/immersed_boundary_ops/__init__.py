@@ -218,8 +218,10 @@ class VirtualBoundaryForcingMPI:
         self.local_lag_grid_position_mismatch_field = z()
         self.local_lag_grid_velocity_mismatch_field = z()
         self.local_lag_grid_forcing_field = z()
-        self.local_lag_grid_position_field = z()
-        self.local_lag_grid_velocity_field = z()
+        # positions and velocities share one allocation so that they travel in one host-to-device copy
+        self._local_lag_grid_state = self.ctx.zeros((2,) + shape, np.float64)
+        self.local_lag_grid_position_field = self._local_lag_grid_state[0]
+        self.local_lag_grid_velocity_field = self._local_lag_grid_state[1]
         if self.grid_dim == 2:
             win = (4, 4, num_lag_nodes)
             self.local_eul_grid_support_of_lag_grid = self.ctx.zeros((2,) + win, np.float64)
@@ -259,12 +261,12 @@ class VirtualBoundaryForcingMPI:
             comm.scatter_global_field(pos, global_lag_grid_position_field)
             comm.scatter_global_field(vel, global_lag_grid_velocity_field)
         if m:
-            self.local_lag_grid_position_field.set(pos)
-            self.local_lag_grid_velocity_field.set(vel)
+            self._local_lag_grid_state.set(np.stack((pos, vel)))
 
     def compute_interaction_force_on_lag_grid(self, local_eul_grid_velocity_field, global_lag_grid_position_field,
-                                              global_lag_grid_velocity_field):
-        """:333-406."""
+                                              global_lag_grid_velocity_field, _download=True):
+        """:333-406.  ``_download=False`` (internal): the caller fetches the forces itself, after it has
+        queued the kernels that follow, so that the device does not idle during the copy."""
         multi = self.mpi_construct.size > 1
         if not self.assume_data_locality and multi:
             self.update_buffers(global_lag_grid_position_field)
@@ -296,7 +298,12 @@ class VirtualBoundaryForcingMPI:
              self.local_num_lag_nodes, comm.dx, comm.coord_shift, comm._substart,
              float(self.virtual_boundary_stiffness_coeff), float(self.virtual_boundary_damping_coeff),
              comm.kernel_type)
-        if not self.assume_data_locality and multi:
+        if _download:
+            self._download_lag_grid_forcing()
+
+    def _download_lag_grid_forcing(self):
+        """Gather of the Lagrangian forcing to the master rank (:402-406)."""
+        if not self.assume_data_locality and self.mpi_construct.size > 1:
             self.mpi_lagrangian_field_communicator.gather_local_field(
                 self.global_lag_grid_forcing_field, self.local_lag_grid_forcing_field.get()
             )
@@ -308,7 +315,8 @@ class VirtualBoundaryForcingMPI:
                                                       global_lag_grid_velocity_field):
         """:408-429."""
         self.compute_interaction_force_on_lag_grid(
-            local_eul_grid_velocity_field, global_lag_grid_position_field, global_lag_grid_velocity_field
+            local_eul_grid_velocity_field, global_lag_grid_position_field, global_lag_grid_velocity_field,
+            _download=self.grid_dim == 2,
         )
         comm = self.eul_lag_grid_communicator
         if self.grid_dim == 2:
@@ -320,6 +328,7 @@ class VirtualBoundaryForcingMPI:
              as_ptr(self.local_lag_grid_forcing_field), as_ptr(self.local_lag_grid_position_field),
              self.local_num_lag_nodes, comm.dx, comm.coord_shift, comm._substart, comm.kernel_type)
         comm.eulerian_grid_ghost_sum(local_field=local_eul_grid_forcing_field)
+        self._download_lag_grid_forcing()  # after the spread has been queued
 
     def compute_interaction_force_on_eul_and_lag_grid_with_eul_grid_forcing_reset(
         self, local_eul_grid_forcing_field, local_eul_grid_velocity_field, global_lag_grid_position_field,
