@@ -305,14 +305,13 @@ constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per 
 #define SMI_FFT_ZCOLS 0
 #endif
 // Row tiles one workgroup of the x kernels walks over (the twiddle set-up is then paid once for
-// all of them).  Measured at 512^3: two tiles take 7 % off x_inv and add 6 % to x_fwd; four or
-// more slow both down.
-#ifndef SMI_FFT_XT_FWD
-#define SMI_FFT_XT_FWD 1
-#endif
-#ifndef SMI_FFT_XT_INV
-#define SMI_FFT_XT_INV 2
-#endif
+// all of them).  Measured: at 512^3 (256-point plan) two tiles take 7 % off x_inv and add 6 % to
+// x_fwd, four or more slow both down; at 384^3 (192-point mixed plan) two tiles cost x_inv 25 %;
+// at 256^3 nothing changes.  So: two tiles for x_inv on power-of-two plans of 256 points and more.
+template <int LG>
+constexpr int x_tiles(bool fwd) {
+  return (!fwd && Plan<LG>::POW2 && LG >= 8) ? 2 : 1;
+}
 #ifndef SMI_FFT_COLS_F32
 #define SMI_FFT_COLS_F32 16
 #endif
@@ -900,8 +899,8 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
   const Cx<T> w1 = tw4[1];  // exp(-i pi / 2L)
-  for (int it = 0; it < SMI_FFT_XT_FWD; ++it) {
-    const int y = (blockIdx.x * SMI_FFT_XT_FWD + it) * TS + t;
+  for (int it = 0; it < x_tiles<LG>(true); ++it) {
+    const int y = (blockIdx.x * x_tiles<LG>(true) + it) * TS + t;
     const bool ok = y < G.ny && item;
     const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
     const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
@@ -953,8 +952,8 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
   const Cx<T> w1 = tw4[1];
-  for (int it = 0; it < SMI_FFT_XT_INV; ++it) {
-    const int y = (blockIdx.x * SMI_FFT_XT_INV + it) * TS + t;
+  for (int it = 0; it < x_tiles<LG>(false); ++it) {
+    const int y = (blockIdx.x * x_tiles<LG>(false) + it) * TS + t;
     const bool ok = y < G.ny && item;
     T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
     const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
@@ -1216,7 +1215,7 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, voi
   // rows start g reals into a padded row: pairs are aligned when g and the row pitch are even
   const int vec2 = (c->g % 2 == 0) && (c->px % 2 == 0) && ((uintptr_t)field % (2 * sizeof(T)) == 0);
   FieldGeo F{c->g, c->px, vec2, (long long)c->plane, (long long)c->vol};
-  const int xt = fwd ? SMI_FFT_XT_FWD : SMI_FFT_XT_INV;
+  const int xt = x_tiles<LG>(fwd);
   dim3 grid((G.ny + TS * xt - 1) / (TS * xt), G.nzl, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[0];
   if (fwd) {
