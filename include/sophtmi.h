@@ -238,6 +238,13 @@ int smi_flow_step_ns3d(smi_ctx* ctx, smi_poisson* p, void* vorticity, void* velo
                        double dt, double nu, double dx, int penalty_width, const double* fac_lo,
                        const double* fac_hi, const double* free_stream, int filter_order,
                        int filter_type);
+/* Optional promise for the next smi_flow_step_ns3d call on ctx (single rank): the forcing field is zero
+ * outside the padded-index box [lo, hi] (z, y, x order, inclusive; lo > hi on an axis = zero everywhere;
+ * NULL, NULL withdraws it).  The step then runs update_vorticity_from_velocity_forcing
+ * (flow_simulators_mpi_3d.py:415-421) and the forcing reset (:422-424) only where that box can reach; the
+ * results are those of the full-array operators.  No counterpart in the reference, whose forcing update
+ * always sweeps the whole grid. */
+int smi_set_forcing_support(smi_ctx* ctx, const int* lo_zyx, const int* hi_zyx);
 
 /* ---- 2D flow path --------------------------------------------------------------------
  * Operators of UnboundedFlowSimulator2D (simulator/flow/flow_simulators_mpi_2d.py:166-298) on

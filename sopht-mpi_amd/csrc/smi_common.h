@@ -36,6 +36,10 @@ struct smi_ctx {
   SmiProf* prof;
   void* exchange_user;
   int halo_depth;  // 0: exchange all g ghost planes; d < g: only the d planes next to the interior
+  // Promise for the next fused step (smi_set_forcing_support): the forcing field is zero outside the padded
+  // index box [lo, hi] (z, y, x order, inclusive; lo > hi = zero everywhere).  Consumed by that step.
+  int fbox_valid;
+  int fbox_lo[3], fbox_hi[3];
 };
 
 constexpr int kRedBlocks = 2048;
@@ -113,5 +117,8 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
 int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add);
+// forcing update and forcing reset restricted to the rows and planes the support box can reach
+int smi_forcing_update_boxed_impl(smi_ctx* c, void* vorticity, void* forcing, double prefactor);
+int smi_forcing_zero_boxed_impl(smi_ctx* c, void* forcing);
 // true when this context has neighbours to exchange with
 static inline bool smi_multi_rank(const smi_ctx* c) { return c->nranks > 1; }

@@ -199,12 +199,19 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
 //   C = { ext(z), ext(y), face(x) }                 the two x boxes
 // (no band zeroing: update_vorticity_from_velocity_forcing_mpi_3d.py has no PROC_NULL logic).
 // MODE 0 on the 16-byte path is served by k_curl_tiled; this kernel remains its scalar-path form.
+// The launch may cover only part of the array (MODE 1 with a known support of f): lanes start at flat
+// plane offset q_begin and stop before q_end, planes run from z_begin to z_end - 1.
+struct CurlRange {
+  long long q_begin, q_end;
+  int z_begin, z_end;
+};
 template <typename T, int V, int MODE>
-__global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f, T pref, Geo G, int zchunk) {
-  long long q;
-  int y, x0;
+__global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f, T pref, Geo G, int zchunk,
+                                                 CurlRange R) {
   const Blk B = xcd_block<false>();
-  if (!lane_pos<V>(G, B, q, y, x0)) return;
+  const long long q = R.q_begin + ((long long)B.x * blockDim.x + threadIdx.x) * V;
+  if (q >= R.q_end) return;
+  const int y = (int)(q / G.px), x0 = (int)(q - (long long)y * G.px);
   const T* fx = f + q;
   const T* fy = f + G.vol + q;
   const T* fz = f + 2 * G.vol + q;
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
     mB[e] = MODE != 0 && ((yf && xc) || (ye && xf));
     any |= mA[e] || mB[e];
   }
-  int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  int z0 = R.z_begin + B.y * zchunk, z1 = min(z0 + zchunk, R.z_end);
   int zs, ze;
   if (MODE == 0) {
     zs = max(z0, G.zlo_c);
@@ -1188,10 +1195,12 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
       added = true;
     } else if (vec_ok<T>(c, out, f)) {
       LaunchShape s = plan<4>(c, 1);
-      k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
+      k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
+                                                           CurlRange{0, G.plane, 0, G.pz});
     } else {
       LaunchShape s = plan<1>(c, 1);
-      k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk);
+      k_curl<T, 1, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
+                                                           CurlRange{0, G.plane, 0, G.pz});
     }
     });
     SMI_LAUNCH_CHECK();
@@ -1203,6 +1212,67 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
 // u = prefactor * curl(field) + add on the whole array (add may be null)
 int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add) {
   return run_curl<0>(c, curl, field, prefactor, add);
+}
+
+namespace {
+// rows [y0, y1] x planes [z0, z1] of every component := 0
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_zero_rows(T* __restrict__ f, Geo G, int y0, int nrows, int z0) {
+  // grid.y = plane, grid.z = component; the rows of one plane are one contiguous run
+  T* p = f + (long long)blockIdx.z * G.vol + (long long)(z0 + blockIdx.y) * G.plane + (long long)y0 * G.px;
+  const long long n = (long long)nrows * G.px;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    p[i] = T(0);
+}
+
+// the support box of the forcing promised for this step, clipped to the array: false when it is empty
+bool forcing_box(const smi_ctx* c, int margin, int (&lo)[3], int (&hi)[3]) {
+  const int p[3] = {c->pz, c->py, c->px};
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = c->fbox_lo[a] - margin < 0 ? 0 : c->fbox_lo[a] - margin;
+    hi[a] = c->fbox_hi[a] + margin > p[a] - 1 ? p[a] - 1 : c->fbox_hi[a] + margin;
+    if (c->fbox_lo[a] > c->fbox_hi[a] || lo[a] > hi[a]) return false;
+  }
+  return true;
+}
+}  // namespace
+
+// w += p curl(f) where f is zero outside the promised box: only the cells within one cell of the box
+// can change, so the kernel runs over those rows and planes only (whole rows: they are contiguous).
+int smi_forcing_update_boxed_impl(smi_ctx* c, void* vorticity, void* forcing, double prefactor) {
+  SMI_REQUIRE(c->fbox_valid && c->nranks == 1, "boxed forcing update without a support box");
+  int lo[3], hi[3];
+  if (!forcing_box(c, 1, lo, hi)) return 0;  // zero forcing: nothing to add
+  Geo G = make_geo(c);
+  bool ok = false;
+  SMI_DISPATCH(c, { ok = vec_ok<T>(c, vorticity, forcing); });
+  if (!ok) return smi_update_vorticity_from_velocity_forcing(c, vorticity, forcing, prefactor);
+  const int nz = hi[0] - lo[0] + 1, nrows = hi[1] - lo[1] + 1;
+  const long long lanes = (long long)nrows * G.px / 4;
+  const int zchunk = nz < 16 ? nz : 16;
+  dim3 grid((unsigned)((lanes + kBlock - 1) / kBlock), (unsigned)((nz + zchunk - 1) / zchunk), 1);
+  const CurlRange R{(long long)lo[1] * G.px, (long long)(hi[1] + 1) * G.px, lo[0], hi[0] + 1};
+  SmiProfScope prof(c, PROF_CURL_UPDATE, 9.0 * nz * nrows * G.px * smi_elem_size(c));
+  SMI_DISPATCH(c, {
+    k_curl<T, 4, 1><<<grid, kBlock, 0, c->stream>>>((T*)vorticity, (const T*)forcing, (T)prefactor, G, zchunk, R);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int smi_forcing_zero_boxed_impl(smi_ctx* c, void* forcing) {
+  SMI_REQUIRE(c->fbox_valid && c->nranks == 1, "boxed forcing reset without a support box");
+  int lo[3], hi[3];
+  if (!forcing_box(c, 0, lo, hi)) return 0;
+  Geo G = make_geo(c);
+  const int nz = hi[0] - lo[0] + 1, nrows = hi[1] - lo[1] + 1;
+  const long long n = (long long)nrows * G.px;
+  const int bx = (int)((n + kBlock - 1) / kBlock < 64 ? (n + kBlock - 1) / kBlock : 64);
+  SMI_DISPATCH(c, {
+    k_zero_rows<T><<<dim3(bx, nz, 3), kBlock, 0, c->stream>>>((T*)forcing, G, lo[1], nrows, lo[0]);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int smi_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vorticity, void* forcing,

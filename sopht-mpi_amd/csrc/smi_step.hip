@@ -22,7 +22,27 @@ extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, v
   const int rc = flow_step_body(c, p, vorticity, velocity, stream_func, buffer_vector, buffer_scalar, forcing, dt, nu,
                                 dx, penalty_width, fac_lo, fac_hi, free_stream, filter_order, filter_type);
   c->halo_depth = saved;
+  c->fbox_valid = 0;  // the promise covered this step only
   return rc;
+}
+
+// Promise for the NEXT smi_flow_step_ns3d on this context: its forcing field is exactly zero outside the
+// padded-index box [lo, hi] (z, y, x order, inclusive); lo[a] > hi[a] for any axis means zero everywhere;
+// null pointers withdraw the promise.  The step then updates the vorticity and resets the forcing only on
+// the planes and rows that box can reach (a body's forcing occupies a few percent of the grid).  Single
+// rank only: across slabs the ghost sum brings in forcing from nodes this rank does not see, and the
+// promise is ignored.
+extern "C" int smi_set_forcing_support(smi_ctx* c, const int* lo_zyx, const int* hi_zyx) {
+  SMI_REQUIRE(c, "smi_set_forcing_support: null context");
+  SMI_REQUIRE((lo_zyx == nullptr) == (hi_zyx == nullptr), "smi_set_forcing_support: give both corners or neither");
+  c->fbox_valid = 0;
+  if (!lo_zyx || c->nranks > 1) return 0;
+  for (int a = 0; a < 3; ++a) {
+    c->fbox_lo[a] = lo_zyx[a];
+    c->fbox_hi[a] = hi_zyx[a];
+  }
+  c->fbox_valid = 1;
+  return 0;
 }
 
 static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
@@ -42,7 +62,11 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
     pref_diff = nu * dt / dx / dx;
     pref_vel = 0.5 / dx;
   }
-  if (forcing) SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, forcing, pref_curl));
+  const bool boxed = forcing && c->fbox_valid && c->nranks == 1;
+  if (boxed)
+    SMI_CHECK(smi_forcing_update_boxed_impl(c, vorticity, forcing, pref_curl));
+  else if (forcing)
+    SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, forcing, pref_curl));
   // Advection and diffusion ping-pong between arrays so each runs as a single pass: the
   // advected vorticity w + dt/(2dx) curl(u x w) lands in buffer_vector (u x w itself only ever
   // exists in registers) and the diffusion step brings it back into vorticity.
@@ -64,7 +88,9 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
   SMI_CHECK(smi_poisson_vector_solve(p, stream_func, vorticity));
   // curl and the free stream in one pass over the velocity array
   SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream));
-  if (forcing) {
+  if (boxed) {
+    SMI_CHECK(smi_forcing_zero_boxed_impl(c, forcing));
+  } else if (forcing) {
     double z3[3] = {0, 0, 0};
     SMI_CHECK(smi_set_fixed_val(c, forcing, 3, z3));
   }

@@ -163,14 +163,36 @@ class DeviceContext:
             pass
 
 
+EMPTY_SUPPORT = "empty"
+
+
 class _Allocation:
-    """Owns one device allocation; views keep it alive."""
+    """Owns one device allocation; views keep it alive.
+
+    ``support`` records what is known about where the contents are non-zero: ``EMPTY_SUPPORT`` (all
+    zero), a ``(lo, hi)`` pair of inclusive index corners, or ``None`` (unknown).  Handing out the
+    device pointer makes it unknown, because whoever receives the pointer may write anywhere; only
+    the writers that state their footprint (the immersed-boundary spread, the fused flow step) ask
+    for the pointer with the record kept.
+    """
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
         p = C.c_void_p()
         call("smi_malloc", ctx.handle, nbytes, C.byref(p))
         self.ptr = p.value
+        self.support = None
+
+    def widen_support(self, lo, hi):
+        """The contents may now be non-zero inside [lo, hi] as well."""
+        if self.support is None:
+            return
+        lo, hi = tuple(int(v) for v in lo), tuple(int(v) for v in hi)
+        if self.support == EMPTY_SUPPORT:
+            self.support = (lo, hi)
+        else:
+            old_lo, old_hi = self.support
+            self.support = (tuple(min(a, b) for a, b in zip(old_lo, lo)), tuple(max(a, b) for a, b in zip(old_hi, hi)))
 
     def __del__(self):
         try:
@@ -196,20 +218,31 @@ class DeviceField:
             self._alloc = _Allocation(ctx, max(self.nbytes, 16))
             self._offset = 0
             if zero and self.nbytes:
-                call("smi_memset_zero", ctx.handle, self.ptr, self.nbytes)
+                call("smi_memset_zero", ctx.handle, self.tracked_ptr(), self.nbytes)
+                self._alloc.support = EMPTY_SUPPORT
         else:
             self._alloc = _alloc
             self._offset = _offset
 
     @property
     def ptr(self):
+        """Device pointer for a caller that may write through it: the support record is dropped."""
+        self._alloc.support = None
         return C.c_void_p(self._alloc.ptr + self._offset)
+
+    def tracked_ptr(self):
+        """Device pointer for readers, and for writers that update ``support`` themselves."""
+        return C.c_void_p(self._alloc.ptr + self._offset)
+
+    @property
+    def support(self):
+        return self._alloc.support
 
     # -- host access --------------------------------------------------------------
     def get(self):
         out = np.empty(self.shape, dtype=self.dtype)
         if self.nbytes:
-            call("smi_memcpy_d2h", self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes)
+            call("smi_memcpy_d2h", self.ctx.handle, out.ctypes.data, self.tracked_ptr(), self.nbytes)
         return out
 
     def set(self, values):
@@ -252,7 +285,7 @@ class DeviceField:
             if isinstance(values, DeviceField):
                 if values.shape != self.shape or values.dtype != self.dtype:
                     raise ValueError("shape / dtype mismatch in device copy")
-                call("smi_memcpy_d2d", self.ctx.handle, self.ptr, values.ptr, self.nbytes)
+                call("smi_memcpy_d2d", self.ctx.handle, self.ptr, values.tracked_ptr(), self.nbytes)
             else:
                 self.set(values)
             return
@@ -262,7 +295,7 @@ class DeviceField:
 
     def copy(self):
         out = DeviceField(self.ctx, self.shape, self.dtype, zero=False)
-        call("smi_memcpy_d2d", self.ctx.handle, out.ptr, self.ptr, self.nbytes)
+        call("smi_memcpy_d2d", self.ctx.handle, out.ptr, self.tracked_ptr(), self.nbytes)
         return out
 
     def fill(self, value):

@@ -4,7 +4,7 @@ import numpy as np
 
 from ... import _lib
 from ..._lib import call, i64array
-from ...device import DeviceField, as_ptr
+from ...device import EMPTY_SUPPORT, DeviceField, as_ptr
 from ...utils import MPILagrangianFieldCommunicator3D
 
 _KERNEL_TYPES = {"cosine": _lib.SMI_DELTA_COSINE, "peskin": _lib.SMI_DELTA_PESKIN}
@@ -324,11 +324,38 @@ class VirtualBoundaryForcingMPI:
                 local_eul_grid_forcing_field, self.local_lag_grid_forcing_field, self.interp_weights,
                 self.nearest_eul_grid_index_to_lag_grid)
             return
-        call("smi_ib_spread_fused", self.ctx.handle, as_ptr(local_eul_grid_forcing_field),
+        # the spread states its footprint (the 4^3 windows of the nodes), so the record of where the forcing
+        # field is non-zero survives and the flow step can skip the rest of the grid
+        footprint = self._spread_footprint(global_lag_grid_position_field)
+        call("smi_ib_spread_fused", self.ctx.handle, local_eul_grid_forcing_field.tracked_ptr(),
              as_ptr(self.local_lag_grid_forcing_field), as_ptr(self.local_lag_grid_position_field),
              self.local_num_lag_nodes, comm.dx, comm.coord_shift, comm._substart, comm.kernel_type)
-        comm.eulerian_grid_ghost_sum(local_field=local_eul_grid_forcing_field)
+        if footprint is None:
+            local_eul_grid_forcing_field._alloc.support = None
+        elif footprint:
+            local_eul_grid_forcing_field._alloc.widen_support(*footprint)
+        if self.mpi_construct.size > 1:
+            comm.eulerian_grid_ghost_sum(local_field=local_eul_grid_forcing_field)
+        else:
+            # one rank: the ghost sum only clears the ghost cells, which takes nothing out of the footprint
+            call("smi_clear_ghost_cells", self.ctx.handle, local_eul_grid_forcing_field.tracked_ptr(), self.grid_dim)
         self._download_lag_grid_forcing()  # after the spread has been queued
+
+    def _spread_footprint(self, global_lag_grid_position_field):
+        """Padded-index corners (z, y, x order) of the cells the spread of these nodes can touch: the
+        window [index - 1, index + 2] of every node (EulerianLagrangianGridCommunicatorMPI3D.py:221-235) with
+        index = floor((X - shift) / dx) + ghost.  ``()`` without nodes, None when it cannot be stated
+        (several ranks: the owner map decides which nodes are local)."""
+        if self.mpi_construct.size > 1 or self.grid_dim != 3:
+            return None
+        pos = np.asarray(global_lag_grid_position_field, dtype=np.float64)
+        if pos.shape[-1] == 0:
+            return ()
+        comm = self.eul_lag_grid_communicator
+        idx = np.floor((pos - comm.coord_shift) / comm.dx).astype(np.int64) + self.ghost_size
+        # one more cell on either side: the device floors the same quotient in its own arithmetic
+        lo, hi = idx.min(axis=1) - 2, idx.max(axis=1) + 3
+        return tuple(lo[::-1]), tuple(hi[::-1])
 
     def compute_interaction_force_on_eul_and_lag_grid_with_eul_grid_forcing_reset(
         self, local_eul_grid_forcing_field, local_eul_grid_velocity_field, global_lag_grid_position_field,
@@ -337,6 +364,7 @@ class VirtualBoundaryForcingMPI:
         """:431-450."""
         call("smi_set_fixed_val" if self.grid_dim == 3 else "smi2d_set_fixed_val", self.ctx.handle,
              as_ptr(local_eul_grid_forcing_field), self.grid_dim, _lib.darray([0.0] * self.grid_dim))
+        local_eul_grid_forcing_field._alloc.support = EMPTY_SUPPORT
         self.compute_interaction_force_on_eul_and_lag_grid(
             local_eul_grid_forcing_field, local_eul_grid_velocity_field, global_lag_grid_position_field,
             global_lag_grid_velocity_field,

@@ -12,7 +12,7 @@ import logging
 import numpy as np
 
 from ..._lib import call, darray
-from ...device import as_ptr
+from ...device import EMPTY_SUPPORT, as_ptr
 from ...numeric.eulerian_grid_ops import (
     UnboundedPoissonSolverMPI3D,
     gen_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d,
@@ -272,7 +272,17 @@ class UnboundedFlowSimulator3D:
         fs = None
         if self.with_free_stream_flow:
             fs = darray(np.asarray(free_stream_velocity, dtype=self.real_t))
-        forcing = as_ptr(self.eul_grid_forcing_field) if self.flow_type == "navier_stokes_with_forcing" else None
+        forcing = None
+        if self.flow_type == "navier_stokes_with_forcing":
+            field = self.eul_grid_forcing_field
+            support = field.support
+            forcing = field.tracked_ptr()
+            if support is not None and self.mpi_construct.size == 1:
+                # the forcing is known to vanish outside a box (only immersed-boundary spreads have written to
+                # it since the last reset): the step sweeps that box instead of the grid
+                box_lo, box_hi = ((1, 1, 1), (0, 0, 0)) if support == EMPTY_SUPPORT else support
+                call("smi_set_forcing_support", self.ctx.handle, (C.c_int * 3)(*box_lo), (C.c_int * 3)(*box_hi))
+            field._alloc.support = EMPTY_SUPPORT  # the step ends with the reset
         order, ftype = 0, 0
         if self.filter_vorticity and self.filter_setting_dict is not None:
             order = int(self.filter_setting_dict["order"])
