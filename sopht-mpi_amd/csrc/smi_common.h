@@ -40,7 +40,14 @@ struct smi_ctx {
   // index box [lo, hi] (z, y, x order, inclusive; lo > hi = zero everywhere).  Consumed by that step.
   int fbox_valid;
   int fbox_lo[3], fbox_hi[3];
+  // max over the interior of |u_x| + |u_y| + |u_z| of the velocity the last fused step wrote, gathered by the
+  // curl kernel itself: kUmaxSlots bit patterns of non-negative reals (device), valid flag, and the value
+  // of the cells outside the curl's compute set (the free stream)
+  void* umax_slots;
+  int umax_valid;
+  double umax_band;
 };
+constexpr int kUmaxSlots = 64;
 
 constexpr int kRedBlocks = 2048;
 
@@ -116,7 +123,8 @@ int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* fiel
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
-int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add);
+int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add,
+                             bool track_max = false);
 // forcing update and forcing reset restricted to the rows and planes the support box can reach
 int smi_forcing_update_boxed_impl(smi_ctx* c, void* vorticity, void* forcing, double prefactor);
 int smi_forcing_zero_boxed_impl(smi_ctx* c, void* forcing);

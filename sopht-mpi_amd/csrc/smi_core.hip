@@ -29,6 +29,7 @@ static int ctx_allocate(smi_ctx* c) {
   SMI_CHECK_HIP(hipMalloc(&c->red_partials, sizeof(double) * (kRedBlocks + 8)));
   SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, sizeof(double) * 8, hipHostMallocDefault));
   SMI_CHECK_HIP(hipMalloc(&c->fac_dev, sizeof(double) * 6 * 64));
+  SMI_CHECK_HIP(hipMalloc(&c->umax_slots, sizeof(unsigned long long) * kUmaxSlots));
   for (int i = 0; i < 2; ++i) SMI_CHECK_HIP(hipMalloc(&c->halo_recv[i], c->halo_cap));
   return 0;
 }
@@ -85,6 +86,7 @@ extern "C" int smi_ctx_destroy(smi_ctx* c) {
   delete c->prof;
   if (c->red_partials) hipFree(c->red_partials);
   if (c->fac_dev) hipFree(c->fac_dev);
+  if (c->umax_slots) hipFree(c->umax_slots);
   if (c->red_host) hipHostFree(c->red_host);
   if (c->ev_a) hipEventDestroy(c->ev_a);
   if (c->ev_b) hipEventDestroy(c->ev_b);
@@ -438,6 +440,32 @@ static int run_reduce(smi_ctx* c, const void* field, int ncomp, double* out) {
 
 extern "C" int smi_reduce_max_abs_sum(smi_ctx* c, const void* vector_field, double* out) {
   return run_reduce<RED_MAX_ABS_SUM3>(c, vector_field, 3, out);
+}
+// The same quantity for the velocity the last smi_flow_step_ns3d wrote, which its curl kernel gathered on
+// the way: no pass over the field.  Fails when no such value is at hand (no fused step yet, or the step ran
+// its scalar-path curl); the caller then reduces the field.  It does not know whether the velocity field
+// has been written since: that is the caller's book-keeping.
+extern "C" int smi_step_velocity_max_abs_sum(smi_ctx* c, double* out) {
+  SMI_REQUIRE(c && out, "smi_step_velocity_max_abs_sum: null argument");
+  SMI_REQUIRE(c->umax_valid, "smi_step_velocity_max_abs_sum: no fused step has recorded the maximum");
+  unsigned long long bits[kUmaxSlots];
+  const size_t es = smi_elem_size(c);
+  SMI_CHECK_HIP(hipMemcpyAsync(bits, c->umax_slots, es * kUmaxSlots, hipMemcpyDeviceToHost, c->stream));
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  double m = c->umax_band;
+  for (int i = 0; i < kUmaxSlots; ++i) {
+    double v;
+    if (c->dtype == SMI_F32) {
+      float f;
+      memcpy(&f, (const char*)bits + 4 * i, 4);
+      v = f;
+    } else {
+      memcpy(&v, (const char*)bits + 8 * i, 8);
+    }
+    if (v > m) m = v;
+  }
+  *out = m;
+  return 0;
 }
 extern "C" int smi_reduce_max(smi_ctx* c, const void* field, int ncomp, double* out) {
   SMI_REQUIRE(ncomp >= 1, "smi_reduce_max: ncomp must be >= 1");

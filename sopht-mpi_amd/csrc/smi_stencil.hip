@@ -743,9 +743,21 @@ template <typename T>
 struct Const3 {
   T x, y, z;
 };
+// Bit pattern of a non-negative real: these order like the reals, so an integer atomic maximum serves.
+__device__ __forceinline__ void atomic_max_nonneg(void* slot, float v) {
+  atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_nonneg(void* slot, double v) {
+  atomicMax(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v));
+}
+
+// `umax` (may be null): kUmaxSlots slots that receive the maximum of |out_x| + |out_y| + |out_z| over the
+// interior cells this launch computes (the time-step rule's max |u|_1, flow_simulators_mpi_3d.py:426-449),
+// one atomic per wave, spread over the slots.
 template <typename T>
 __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out, const T* __restrict__ f, T pref,
-                                                            Geo G, int zchunk, TileShape S, Const3<T> add) {
+                                                            Geo G, int zchunk, TileShape S, Const3<T> add,
+                                                            T* __restrict__ umax) {
   extern __shared__ char smi_tile_smem[];
   T* lds = reinterpret_cast<T*>(smi_tile_smem);
   const Blk B = xcd_block<true>();
@@ -776,6 +788,13 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
   if (!run) return;
   const T* fo = f + L.q;
   const T* fh = f + L.hq;
+  T lmax = T(0);
+  bool inner[4];  // interior cells of this lane's row (ghost rows and columns do not count)
+  {
+    const bool yi = L.own && L.y >= G.g && L.y <= G.py - G.g - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) inner[e] = yi && L.x0 + e >= G.g && L.x0 + e <= G.px - G.g - 1;
+  }
   auto park = [&](int buf, int off, const Vec3<T, 4>& v) {
     T* t = lds + buf * 3 * comp + off;
     st<T, 4>(t, v.x);
@@ -813,6 +832,13 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
       ry.v[e] = (core[e] ? cy : T(0)) + add.y;
       rz.v[e] = (core[e] ? cz : T(0)) + add.z;
     }
+    if (umax && z >= G.g && z <= G.pz - G.g - 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const T s1 = fabs(rx.v[e]) + fabs(ry.v[e]) + fabs(rz.v[e]);
+        lmax = inner[e] ? max(lmax, s1) : lmax;
+      }
+    }
     if (L.own) {
       const long long zo = z * G.plane + L.q;
       st<T, 4>(out + zo, rx);
@@ -835,6 +861,14 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
     if (L.own) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) st<T, 4>(out + k * G.vol + z * G.plane + L.q, band[k]);
+    }
+  }
+  if (umax) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && lmax > T(0)) {
+      const unsigned wave = (blockIdx.x + gridDim.x * blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+      atomic_max_nonneg(umax + (wave & (kUmaxSlots - 1)), lmax);
     }
   }
 }
@@ -1179,11 +1213,15 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
 // add_fixed_val that follows the curl in compute_flow_velocity (flow_simulators_mpi_3d.py:382-393),
 // folded into the store of the tiled kernel; the other paths run it as a second pass.
 template <int MODE>
-static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const double* add = nullptr) {
+static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const double* add = nullptr,
+                    bool track_max = false) {
   SMI_REQUIRE(out != f, "curl operators: output and input must not alias");
   if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
   Geo G = make_geo(c);
   bool added = add == nullptr;
+  c->umax_valid = 0;
+  if (track_max)
+    SMI_CHECK_HIP(hipMemsetAsync(c->umax_slots, 0, sizeof(unsigned long long) * kUmaxSlots, c->stream));
   {
     SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
     SMI_DISPATCH(c, {
@@ -1191,8 +1229,14 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
       const TiledLaunch t = tiled_launch<T>(c, 3, 1);
       SMI_CHECK(allow_lds(k_curl_tiled<T>));
       const Const3<T> a = add ? Const3<T>{(T)add[0], (T)add[1], (T)add[2]} : Const3<T>{T(0), T(0), T(0)};
-      k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S, a);
+      k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S, a,
+                                                                     track_max ? (T*)c->umax_slots : nullptr);
       added = true;
+      if (track_max) {
+        // cells outside the compute set (the zeroed bands) hold the constant alone
+        c->umax_band = (double)(fabs(a.x) + fabs(a.y) + fabs(a.z));
+        c->umax_valid = 1;
+      }
     } else if (vec_ok<T>(c, out, f)) {
       LaunchShape s = plan<4>(c, 1);
       k_curl<T, 4, MODE><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, s.zchunk,
@@ -1210,8 +1254,9 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
 }
 
 // u = prefactor * curl(field) + add on the whole array (add may be null)
-int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add) {
-  return run_curl<0>(c, curl, field, prefactor, add);
+int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add,
+                             bool track_max) {
+  return run_curl<0>(c, curl, field, prefactor, add, track_max);
 }
 
 namespace {

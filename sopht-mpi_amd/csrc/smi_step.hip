@@ -87,7 +87,7 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
   SMI_CHECK(smi_penalise_boundary(c, vorticity, 3, penalty_width, fac_lo, fac_hi));
   SMI_CHECK(smi_poisson_vector_solve(p, stream_func, vorticity));
   // curl and the free stream in one pass over the velocity array
-  SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream));
+  SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream, /*track_max=*/true));
   if (boxed) {
     SMI_CHECK(smi_forcing_zero_boxed_impl(c, forcing));
   } else if (forcing) {

@@ -182,6 +182,9 @@ class _Allocation:
         call("smi_malloc", ctx.handle, nbytes, C.byref(p))
         self.ptr = p.value
         self.support = None
+        # names of by-products of the last writer that are still true of the contents (dropped with the
+        # support record whenever the raw pointer is handed out)
+        self.derived = set()
 
     def widen_support(self, lo, hi):
         """The contents may now be non-zero inside [lo, hi] as well."""
@@ -228,6 +231,7 @@ class DeviceField:
     def ptr(self):
         """Device pointer for a caller that may write through it: the support record is dropped."""
         self._alloc.support = None
+        self._alloc.derived.clear()
         return C.c_void_p(self._alloc.ptr + self._offset)
 
     def tracked_ptr(self):

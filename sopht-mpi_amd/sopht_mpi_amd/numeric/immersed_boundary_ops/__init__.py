@@ -294,7 +294,7 @@ class VirtualBoundaryForcingMPI:
         call("smi_ib_forcing_fused", self.ctx.handle, as_ptr(self.local_lag_grid_forcing_field),
              as_ptr(self.local_lag_grid_velocity_mismatch_field), as_ptr(self.local_lag_grid_flow_velocity_field),
              as_ptr(self.local_lag_grid_position_mismatch_field), as_ptr(self.local_lag_grid_position_field),
-             as_ptr(self.local_lag_grid_velocity_field), as_ptr(local_eul_grid_velocity_field),
+             as_ptr(self.local_lag_grid_velocity_field), local_eul_grid_velocity_field.tracked_ptr(),  # read only
              self.local_num_lag_nodes, comm.dx, comm.coord_shift, comm._substart,
              float(self.virtual_boundary_stiffness_coeff), float(self.virtual_boundary_damping_coeff),
              comm.kernel_type)

@@ -11,7 +11,7 @@ import logging
 
 import numpy as np
 
-from ..._lib import call, darray
+from ..._lib import call, darray, lib
 from ...device import EMPTY_SUPPORT, as_ptr
 from ...numeric.eulerian_grid_ops import (
     UnboundedPoissonSolverMPI3D,
@@ -291,13 +291,18 @@ class UnboundedFlowSimulator3D:
              as_ptr(self.vorticity_field), as_ptr(self.velocity_field), as_ptr(self.stream_func_field),
              as_ptr(self.buffer_vector_field), as_ptr(self.buffer_scalar_field), forcing, float(dt),
              float(self.kinematic_viscosity), float(self.dx), int(self.penalty_zone_width), lo, hi, fs, order, ftype)
+        # the step's curl kernel has gathered max |u|_1 of the velocity it wrote (compute_stable_timestep)
+        self.velocity_field._alloc.derived.add("step_max_abs_sum")
 
     # ------------------------------------------------------------------ diagnostics
     def compute_stable_timestep(self, dt_prefac=1, precision="single"):
         """flow_simulators_mpi_3d.py:426-449 with the |u|_1 maximum reduced on the device."""
         tol = get_test_tol(precision)
         out = C.c_double(0.0)
-        call("smi_reduce_max_abs_sum", self.ctx.handle, as_ptr(self.velocity_field), C.byref(out))
+        fresh = "step_max_abs_sum" in self.velocity_field._alloc.derived
+        if not fresh or lib.smi_step_velocity_max_abs_sum(self.ctx.handle, C.byref(out)) != 0:
+            # the velocity has been written since the last fused step (or there was none): reduce the field
+            call("smi_reduce_max_abs_sum", self.ctx.handle, self.velocity_field.tracked_ptr(), C.byref(out))
         vel_max = self.real_t(out.value)
         dt = min(
             self.CFL * self.dx / (vel_max + tol),

@@ -117,3 +117,34 @@ def test_promise_is_for_one_step_and_one_rank(smi):
     call("smi_set_forcing_support", sim.ctx.handle, None, None)  # withdrawn
     with pytest.raises(SophtMIError):
         call("smi_set_forcing_support", sim.ctx.handle, lo, None)
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("free_stream", [None, [0.7, -0.2, 0.1]])
+def test_step_gathers_the_velocity_maximum(smi, real_t, free_stream):
+    """compute_stable_timestep after a fused step takes max |u|_1 from the step's curl kernel; it must be the
+    value a reduction over the velocity field gives, and any write to the field must send it back there."""
+    from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
+
+    sim = UnboundedFlowSimulator3D(grid_size=(24, 20, 32), x_range=1.0, kinematic_viscosity=1e-3,
+                                   flow_type="navier_stokes", real_t=real_t,
+                                   with_free_stream_flow=free_stream is not None)
+    sim.vorticity_field[...] = 40 * _blob(sim, real_t)
+    sim.compute_flow_velocity(free_stream_velocity=free_stream)
+    assert "step_max_abs_sum" not in sim.velocity_field._alloc.derived
+    for _ in range(3):
+        sim.time_step(dt=1e-3, free_stream_velocity=free_stream)
+        assert "step_max_abs_sum" in sim.velocity_field._alloc.derived
+        dt_fast = sim.compute_stable_timestep()
+        assert "step_max_abs_sum" in sim.velocity_field._alloc.derived, "reading must not drop the by-product"
+        u = sim.velocity_field.get()
+        g = sim.ghost_size
+        want = np.max(np.sum(np.abs(u), axis=0)[g:-g, g:-g, g:-g])
+        _ = sim.velocity_field.ptr  # drop it: the next call reduces the field
+        dt_slow = sim.compute_stable_timestep()
+        assert dt_fast == pytest.approx(dt_slow, rel=1e-6 if real_t == np.float32 else 1e-13)
+        assert dt_fast == pytest.approx(sim.CFL * sim.dx / (want + (1e-4)), rel=1e-5)
+    sim.time_step(dt=1e-3, free_stream_velocity=free_stream)
+    sim.velocity_field[...] = 0  # a host write
+    dt0 = sim.compute_stable_timestep()
+    assert dt0 == pytest.approx(min(sim.CFL * sim.dx / 1e-4, 0.9 * sim.dx**2 / 6 / (1e-3 + 1e-4)), rel=1e-5)
