@@ -1,5 +1,5 @@
 """Condense the per-kernel counter CSVs written by tools/pmc_bench.sh into the JSON that
-bench.py reads (HBM traffic per launch) and DESIGN.md quotes (VALU issue utilisation).
+bench.py reads (HBM traffic per launch, VALU issue utilisation).
 
   python tools/make_counters_json.py <tag> <grid> <out.json>     reads gpurun_out/pmcb_<tag>_{1..4}.csv
 """
