@@ -1,10 +1,15 @@
 #!/bin/bash
-# build_variant.sh NAME "-DFLAG=..."  -> build/var/libsophtmi_NAME.so (only smi_fft.hip recompiled)
+# build_variant.sh NAME FILE "-DFLAG=..."  -> build/var/libsophtmi_NAME.so with csrc/FILE.hip recompiled
+# under the given flags and every other object taken from the regular build (run `make` first)
 set -e
-NAME=$1; shift
+NAME=$1; FILE=$2; shift 2
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Isopht-mpi_amd/csrc -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-result -Wno-unused-value"
 C=sopht-mpi_amd/csrc
 mkdir -p build/var
-/opt/rocm/bin/hipcc $F "$@" -c $C/smi_fft.hip -o build/var/smi_fft_$NAME.o 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $C/smi_core.o $C/smi_stencil.o $C/smi_poisson.o build/var/smi_fft_$NAME.o $C/smi_ib.o $C/smi_comm.o $C/smi_step.o $C/smi_2d.o $C/smi_fftapi.o -o build/var/libsophtmi_$NAME.so -L/opt/rocm/lib -lhipfft -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc $F "$@" -c $C/$FILE.hip -o build/var/${FILE}_$NAME.o 2>/dev/null
+OBJS=""
+for f in smi_core smi_stencil smi_poisson smi_fft smi_ib smi_comm smi_step smi_2d smi_fftapi; do
+  if [ $f = $FILE ]; then OBJS="$OBJS build/var/${FILE}_$NAME.o"; else OBJS="$OBJS $C/$f.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o build/var/libsophtmi_$NAME.so -L/opt/rocm/lib -lhipfft -lrccl -Wl,-rpath,/opt/rocm/lib
 echo built build/var/libsophtmi_$NAME.so
