@@ -1,0 +1,77 @@
+// Micro-benchmark: does data just written by one kernel come back faster than from HBM when the next
+// kernel reads it, as long as the working set stays inside the 256 MiB Infinity Cache?
+// A producer kernel streams `bytes` into a buffer (plain or non-temporal stores), a consumer kernel
+// then reads the same range (plain or non-temporal loads).  Between the two nothing else runs.
+// The last rows read a buffer far larger than the cache in the same way (the HBM reference).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/micro/ic_reuse.hip -o build/ic_reuse
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float v4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ void __launch_bounds__(256) k_write(v4* p, size_t n, float s) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    v4 v = {s, s + 1, s + 2, (float)i};
+    if (NT) __builtin_nontemporal_store(v, p + i); else p[i] = v;
+  }
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) k_read(const v4* p, size_t n, float* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  v4 acc = {0, 0, 0, 0};
+  for (; i < n; i += stride) acc += NT ? __builtin_nontemporal_load(p + i) : p[i];
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+// in place: read, modify, write back (what the z convolution does to its tile)
+__global__ void __launch_bounds__(256) k_rmw(v4* p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = p[i] * 1.0001f;
+}
+
+int main() {
+  const size_t big = (size_t)4 << 30;
+  v4* buf;
+  float* out;
+  if (hipMalloc(&buf, big) != hipSuccess || hipMalloc(&out, 4) != hipSuccess) return 1;
+  hipEvent_t e[4];
+  for (auto& x : e) hipEventCreate(&x);
+  const int blocks = 256 * 8;
+  k_write<false><<<blocks, 256>>>(buf, big / 16, 1.0f);
+  hipDeviceSynchronize();
+  for (size_t mb : {32, 64, 128, 192, 256, 512, 2048}) {
+    const size_t n = (mb << 20) / 16;
+    for (int mode = 0; mode < 4; ++mode) {
+      const bool ntw = mode & 1, ntr = mode & 2;
+      float best_w = 1e9f, best_r = 1e9f, best_m = 1e9f;
+      for (int rep = 0; rep < 5; ++rep) {
+        // evict: sweep a far-away 1.5 GB region
+        k_read<false><<<blocks, 256>>>(buf + (big / 16) / 2, ((size_t)1536 << 20) / 16, out);
+        hipEventRecord(e[0]);
+        if (ntw) k_write<true><<<blocks, 256>>>(buf, n, (float)rep); else k_write<false><<<blocks, 256>>>(buf, n, (float)rep);
+        hipEventRecord(e[1]);
+        k_rmw<<<blocks, 256>>>(buf, n);
+        hipEventRecord(e[2]);
+        if (ntr) k_read<true><<<blocks, 256>>>(buf, n, out); else k_read<false><<<blocks, 256>>>(buf, n, out);
+        hipEventRecord(e[3]);
+        hipEventSynchronize(e[3]);
+        float w, m, r;
+        hipEventElapsedTime(&w, e[0], e[1]);
+        hipEventElapsedTime(&m, e[1], e[2]);
+        hipEventElapsedTime(&r, e[2], e[3]);
+        best_w = w < best_w ? w : best_w;
+        best_m = m < best_m ? m : best_m;
+        best_r = r < best_r ? r : best_r;
+      }
+      const double gb = (double)(mb << 20) / 1e9;
+      printf("%5zu MB  stores %s loads %s : write %6.0f GB/s   in-place rmw %6.0f GB/s (r+w)   read %6.0f GB/s\n", mb,
+             ntw ? "nt   " : "plain", ntr ? "nt   " : "plain", gb / (best_w * 1e-3), 2 * gb / (best_m * 1e-3),
+             gb / (best_r * 1e-3));
+    }
+  }
+  return 0;
+}
