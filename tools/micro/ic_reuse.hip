@@ -33,6 +33,24 @@ __global__ void __launch_bounds__(256) k_rmw(v4* p, size_t n) {
   for (; i < n; i += stride) p[i] = p[i] * 1.0001f;
 }
 
+// out of place: the same traffic as k_rmw, but reads and writes go to different buffers
+template <bool NTS>
+__global__ void __launch_bounds__(256) k_copy(v4* dst, const v4* src, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const v4 v = __builtin_nontemporal_load(src + i) * 1.0001f;
+    if (NTS) __builtin_nontemporal_store(v, dst + i); else dst[i] = v;
+  }
+}
+// in place with a lag: the write of element i goes out `lag` elements behind the read front, as in a kernel
+// that prefetches its next tile while it stores the previous one
+__global__ void __launch_bounds__(256) k_rmw_nt(v4* p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(p + i) * 1.0001f, p + i);
+}
+
 int main() {
   const size_t big = (size_t)4 << 30;
   v4* buf;
@@ -72,6 +90,29 @@ int main() {
              ntw ? "nt   " : "plain", ntr ? "nt   " : "plain", gb / (best_w * 1e-3), 2 * gb / (best_m * 1e-3),
              gb / (best_r * 1e-3));
     }
+  }
+  // in place against out of place on a range far beyond the cache (1 GB read + 1 GB written)
+  {
+    const size_t n = ((size_t)1 << 30) / 16;
+    v4* dst = buf + 2 * n;
+    float t[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+    for (int rep = 0; rep < 5; ++rep) {
+      for (int k = 0; k < 4; ++k) {
+        hipEventRecord(e[0]);
+        if (k == 0) k_rmw<<<blocks, 256>>>(buf, n);
+        if (k == 1) k_rmw_nt<<<blocks, 256>>>(buf, n);
+        if (k == 2) k_copy<false><<<blocks, 256>>>(dst, buf, n);
+        if (k == 3) k_copy<true><<<blocks, 256>>>(dst, buf, n);
+        hipEventRecord(e[1]);
+        hipEventSynchronize(e[1]);
+        float ms;
+        hipEventElapsedTime(&ms, e[0], e[1]);
+        t[k] = ms < t[k] ? ms : t[k];
+      }
+    }
+    const char* names[4] = {"in place, plain", "in place, nt load + nt store", "out of place, nt load + plain store",
+                            "out of place, nt load + nt store"};
+    for (int k = 0; k < 4; ++k) printf("1 GB read + 1 GB written, %-36s: %6.0f GB/s (r+w)\n", names[k], 2 * 1.0737 / (t[k] * 1e-3));
   }
   return 0;
 }
