@@ -14,7 +14,7 @@ LDLIBS  := -L/opt/rocm/lib -lhipfft -lrccl -Wl,-rpath,/opt/rocm/lib
 
 all: $(OUT)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/smi_common.h $(CSRC)/smi_poisson.h include/sophtmi.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/sophtmi.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OUT): $(OBJS)
