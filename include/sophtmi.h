@@ -182,6 +182,16 @@ int smi_poisson_create(smi_poisson** out, smi_ctx* ctx, int global_nz, int globa
 int smi_poisson_destroy(smi_poisson* p);
 int smi_poisson_solve(smi_poisson* p, void* solution, const void* rhs);
 int smi_poisson_vector_solve(smi_poisson* p, void* solution, const void* rhs);
+/* smi_poisson_solve for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same kernels and
+ * bit-identical results, but the spectral work buffers come from a fixed 64 MiB array inside the library
+ * (one per GPU, held until the process ends) instead of the buffers smi_poisson_create allocated; the call
+ * itself makes no hipMalloc / hipFree or other allocating call.  Needs a single-rank solver created with
+ * SMI_POISSON_PRUNED whose scalar work space fits (up to 128^3 in single, 64^3 in double precision); larger
+ * grids are rejected with an error.  Every call on a GPU shares that GPU's array: calls that overlap on one
+ * GPU (two contexts, two streams) race.  smi_poisson_noalloc_capacity: the size of the array in bytes. */
+int smi_poisson_solve_noalloc(smi_poisson* p, void* solution, const void* rhs);
+size_t smi_poisson_noalloc_capacity(void);
 /* debug / test: download the compact Green's-function spectrum */
 size_t smi_poisson_greens_size(smi_poisson* p);
 int smi_poisson_greens_download(smi_poisson* p, void* host);

@@ -128,5 +128,7 @@ int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefact
 // forcing update and forcing reset restricted to the rows and planes the support box can reach
 int smi_forcing_update_boxed_impl(smi_ctx* c, void* vorticity, void* forcing, double prefactor);
 int smi_forcing_zero_boxed_impl(smi_ctx* c, void* forcing);
+// looks up, once per device, the device address of the fixed scratch array of smi_poisson_solve_noalloc
+int smi_pruned_scratch_init(int device);
 // true when this context has neighbours to exchange with
 static inline bool smi_multi_rank(const smi_ctx* c) { return c->nranks > 1; }

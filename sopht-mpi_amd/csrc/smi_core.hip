@@ -46,6 +46,7 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   SMI_REQUIRE(((nz == 1 && nranks == 1) || nz >= 2 * ghost) && ny >= 2 * ghost && nx >= 2 * ghost,
               "smi_ctx_create: local grid %d %d %d smaller than 2*ghost", nz, ny, nx);
   SMI_CHECK_HIP(hipSetDevice(device));
+  SMI_CHECK(smi_pruned_scratch_init(device));
   smi_ctx* c = new smi_ctx();
   memset(c, 0, sizeof(*c));
   c->device = device;

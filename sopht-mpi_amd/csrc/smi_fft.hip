@@ -1298,3 +1298,69 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
   });
   return 0;
 }
+
+// ------------------------------------------------------------------ solve without allocation
+// smi_poisson_solve_noalloc: the scalar single-rank solve above with its two spectral work buffers (bufA after
+// the x pass, bufB after the y pass) taken from this fixed array instead of the buffers smi_poisson_create
+// allocated.  The array is one per GPU and is shared by every call on that GPU; it keeps the contents of the
+// last call, so each call clears the part it uses first (the transforms leave the pad columns of a row alone and
+// count on them being finite).  Two calls that overlap on one GPU race on it.
+constexpr size_t kScratchBytes = 64ull << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kScratchMaxDevices = 64;
+// device address of `scratch` on each GPU (the name itself is only a host-side handle for hipGetSymbolAddress)
+static void* g_scratch_ptr[kScratchMaxDevices];
+
+// Called by smi_ctx_create with the context's device current.
+int smi_pruned_scratch_init(int device) {
+  SMI_REQUIRE(device >= 0 && device < kScratchMaxDevices, "device index %d beyond %d", device, kScratchMaxDevices);
+  if (g_scratch_ptr[device]) return 0;
+  void* ptr = nullptr;
+  SMI_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  SMI_REQUIRE(ptr, "hipGetSymbolAddress returned a null address for the solver scratch");
+  g_scratch_ptr[device] = ptr;
+  return 0;
+}
+
+namespace {
+__global__ void __launch_bounds__(256) k_scratch_clear(uint4* __restrict__ p, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+}  // namespace
+
+size_t smi_pruned_noalloc_capacity(void) { return kScratchBytes; }
+
+int smi_pruned_solve_noalloc(smi_poisson* p, void* solution, const void* rhs) {
+  smi_ctx* c = p->ctx;
+  PrunedState* s = p->pruned;
+  SMI_REQUIRE(s, "smi_poisson_solve_noalloc: the solver was not created with SMI_POISSON_PRUNED");
+  const PGeo& G = s->G;
+  SMI_REQUIRE(G.P == 1, "smi_poisson_solve_noalloc: single rank only (this context is rank %d of %d)", c->rank, G.P);
+  void* base = g_scratch_ptr[c->device];
+  SMI_REQUIRE(base, "smi_poisson_solve_noalloc: no scratch address for device %d", c->device);
+  // one component of the work buffers, sized as smi_pruned_create sizes three
+  const size_t cs = 2 * smi_elem_size(c);
+  const size_t bytesA = (((size_t)G.nzl * G.ny * G.KXA + 16) * cs + 255) / 256 * 256;
+  const size_t bytesB = ((size_t)G.nz * 2 * G.ny * G.KXP * cs + 255) / 256 * 256;
+  SMI_REQUIRE(bytesA + bytesB <= kScratchBytes,
+              "smi_poisson_solve_noalloc: a %d x %d x %d solve needs %zu bytes of work space, the fixed scratch "
+              "holds %zu (64^3 in double and 128^3 in single precision fit); use smi_poisson_solve",
+              G.nz, G.ny, G.nx, bytesA + bytesB, kScratchBytes);
+  const size_t n16 = (bytesA + bytesB) / 16;
+  const size_t want = (n16 + 255) / 256;
+  k_scratch_clear<<<(int)(want < 2048 ? want : 2048), 256, 0, c->stream>>>((uint4*)base, n16);
+  SMI_LAUNCH_CHECK();
+  PrunedState t = *s;  // same plans, twiddles and Green's table; only the work buffers differ
+  t.bufA = base;
+  t.bufT = base;
+  t.bufB = (char*)base + bytesA;
+  SMI_DISPATCH(c, {
+    LG_SWITCH(t.lgx, SMI_CHECK((launch_rows<T, LG>(c, &t, true, 0, 1, (void*)rhs)));)
+    LG_SWITCH(t.lgy, SMI_CHECK((launch_cols<T, LG>(c, &t, 0, 0, 1)));)
+    LG_SWITCH(t.lgz, SMI_CHECK((launch_cols<T, LG>(c, &t, 1, 0, 1)));)
+    LG_SWITCH(t.lgy, SMI_CHECK((launch_cols<T, LG>(c, &t, 2, 0, 1)));)
+    LG_SWITCH(t.lgx, SMI_CHECK((launch_rows<T, LG>(c, &t, false, 0, 1, solution)));)
+  });
+  return 0;
+}

@@ -20,3 +20,6 @@ int smi_pruned_destroy(smi_poisson* p);
 int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp);
 size_t smi_pruned_greens_size(smi_poisson* p);
 int smi_pruned_greens_download(smi_poisson* p, void* host);
+// the solve on the library's fixed per-GPU scratch array (smi_fft.hip)
+int smi_pruned_solve_noalloc(smi_poisson* p, void* solution, const void* rhs);
+size_t smi_pruned_noalloc_capacity(void);

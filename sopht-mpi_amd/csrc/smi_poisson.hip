@@ -275,6 +275,15 @@ extern "C" int smi_poisson_solve(smi_poisson* p, void* solution, const void* rhs
   return p->backend == SMI_POISSON_ROCFFT ? rocfft_solve(p, solution, rhs) : smi_pruned_solve(p, solution, rhs, 1);
 }
 
+extern "C" int smi_poisson_solve_noalloc(smi_poisson* p, void* solution, const void* rhs) {
+  SMI_REQUIRE(p && solution && rhs, "smi_poisson_solve_noalloc: null argument");
+  SMI_REQUIRE(p->backend == SMI_POISSON_PRUNED,
+              "smi_poisson_solve_noalloc: only solvers created with SMI_POISSON_PRUNED (hipFFT may allocate)");
+  return smi_pruned_solve_noalloc(p, solution, rhs);
+}
+
+extern "C" size_t smi_poisson_noalloc_capacity(void) { return smi_pruned_noalloc_capacity(); }
+
 extern "C" int smi_poisson_vector_solve(smi_poisson* p, void* solution, const void* rhs) {
   SMI_REQUIRE(p && solution && rhs, "smi_poisson_vector_solve: null argument");
   if (p->backend == SMI_POISSON_PRUNED) return smi_pruned_solve(p, solution, rhs, 3);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "smi_poisson_destroy": [_p],
     "smi_poisson_solve": [_p, _p, _p],
     "smi_poisson_vector_solve": [_p, _p, _p],
+    "smi_poisson_solve_noalloc": [_p, _p, _p],
     "smi_poisson_greens_download": [_p, _p],
     "smi_fft_create": [_pp, _p, _i, _i, _i],
     "smi_fft_destroy": [_p],
@@ -125,6 +126,7 @@ _SPECIAL = {
     "smi_version": (C.c_int, []),
     "smi_prof_num_slots": (C.c_int, []),
     "smi_poisson_greens_size": (C.c_size_t, [_p]),
+    "smi_poisson_noalloc_capacity": (C.c_size_t, []),
 }
 
 for _name, _args in SIGNATURES.items():
