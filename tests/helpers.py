@@ -1,10 +1,24 @@
 """Shared helpers of the GPU parity tests: tolerances and small factories."""
+import json
+import os
+
 import numpy as np
 
 # Floating-point parity bar.  north_star: "matching reference vorticity to rtol 1e-5" (f32).
 # Pointwise rtol is meaningless where a field crosses zero, so the bound is relative to the
 # largest magnitude of the expected array: |got - want| <= TOL * max|want|.
 TOL = {np.dtype(np.float32): 1e-5, np.dtype(np.float64): 1e-12}
+
+
+_ERRLOG = os.environ.get("SMI_TEST_ERRLOG")
+
+
+def _record(what, real_t, rel_err, factor):
+    """With SMI_TEST_ERRLOG=<file>: append the measured relative error of every comparison (used to set the bounds)."""
+    if _ERRLOG:
+        with open(_ERRLOG, "a") as fh:
+            fh.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what,
+                                 "dtype": np.dtype(real_t).name, "rel_err": rel_err, "factor": factor}) + "\n")
 
 
 def assert_close(got, want, real_t, scale=None, factor=1.0, what=""):
@@ -14,6 +28,7 @@ def assert_close(got, want, real_t, scale=None, factor=1.0, what=""):
     ref = float(np.max(np.abs(want))) if scale is None else float(scale)
     tol = factor * TOL[np.dtype(real_t)] * max(ref, np.finfo(np.float64).tiny)
     err = float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64)))) if got.size else 0.0
+    _record(what, real_t, err / max(ref, np.finfo(np.float64).tiny), factor)
     assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e} (scale {ref:.3e})"
 
 
