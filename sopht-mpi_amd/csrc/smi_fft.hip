@@ -1095,6 +1095,12 @@ static int fold_greens_table(smi_ctx* c, PrunedState* s, const void* ghat) {
   return 0;
 }
 
+// grids the pruned back end has plans for (what smi_poisson_supports reports)
+bool smi_pruned_supports(int gnz, int gny, int gnx) {
+  return gnx % 2 == 0 && plan_key(gnx / 2) && plan_key(gny) && plan_key(gnz) && gnx >= 16 && gny >= 8 && gnz >= 8 &&
+         gnx <= 4096 && gny <= 2048 && gnz <= 2048;
+}
+
 int smi_pruned_create(smi_poisson* p) {
   smi_ctx* c = p->ctx;
   SMI_REQUIRE(p->gnx % 2 == 0 && plan_key(p->gnx / 2) && plan_key(p->gny) && plan_key(p->gnz) && p->gnx >= 16 &&

@@ -15,6 +15,7 @@ struct smi_poisson {
   PrunedState* pruned;
 };
 
+bool smi_pruned_supports(int gnz, int gny, int gnx);
 int smi_pruned_create(smi_poisson* p);
 int smi_pruned_destroy(smi_poisson* p);
 int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp);

@@ -261,6 +261,13 @@ extern "C" int smi_poisson_create(smi_poisson** out, smi_ctx* ctx, int global_nz
   return 0;
 }
 
+extern "C" int smi_poisson_supports(int global_nz, int global_ny, int global_nx, int nranks, int backend) {
+  if (global_nz < 1 || global_ny < 1 || global_nx < 1 || nranks < 1 || global_nz % nranks != 0) return 0;
+  if (backend == SMI_POISSON_ROCFFT) return nranks == 1;
+  if (backend == SMI_POISSON_PRUNED) return smi_pruned_supports(global_nz, global_ny, global_nx) ? 1 : 0;
+  return 0;
+}
+
 extern "C" int smi_poisson_destroy(smi_poisson* p) {
   if (!p) return 0;
   hipSetDevice(p->ctx->device);

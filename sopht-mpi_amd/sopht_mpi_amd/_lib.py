@@ -127,6 +127,7 @@ _SPECIAL = {
     "smi_prof_num_slots": (C.c_int, []),
     "smi_poisson_greens_size": (C.c_size_t, [_p]),
     "smi_poisson_noalloc_capacity": (C.c_size_t, []),
+    "smi_poisson_supports": (C.c_int, [_i, _i, _i, _i, _i]),
 }
 
 for _name, _args in SIGNATURES.items():

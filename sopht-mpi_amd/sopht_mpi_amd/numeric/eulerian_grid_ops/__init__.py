@@ -265,20 +265,22 @@ class UnboundedPoissonSolverMPI3D:
         self.dx = real_t(x_range / grid_size_x)
         self.ctx = mpi_construct.device_context(ghost_size)
         names = {"rocfft": _lib.SMI_POISSON_ROCFFT, "pruned": _lib.SMI_POISSON_PRUNED}
-        order = [backend] if backend is not None else ["pruned", "rocfft"]
-        err = None
+        if backend is None:
+            backend = "pruned" if self.backend_supports("pruned", grid_size_z, grid_size_y, grid_size_x,
+                                                        mpi_construct.size) else "rocfft"
+        if backend not in names:
+            raise ValueError(f"unknown Poisson back end {backend!r}")
         self.handle = None
-        for name in order:
-            h = C.c_void_p()
-            try:
-                call("smi_poisson_create", C.byref(h), self.ctx.handle, int(grid_size_z), int(grid_size_y),
-                     int(grid_size_x), float(self.dx), float(x_range), names[name])
-                self.handle, self.backend = h, name
-                break
-            except _lib.SophtMIError as exc:
-                err = exc
-        if self.handle is None:
-            raise err
+        h = C.c_void_p()
+        call("smi_poisson_create", C.byref(h), self.ctx.handle, int(grid_size_z), int(grid_size_y),
+             int(grid_size_x), float(self.dx), float(x_range), names[backend])
+        self.handle, self.backend = h, backend
+
+    @staticmethod
+    def backend_supports(backend, grid_size_z, grid_size_y, grid_size_x, nranks=1):
+        """Whether ``backend`` ("rocfft" / "pruned") takes this global grid on ``nranks`` z-slabs."""
+        code = {"rocfft": _lib.SMI_POISSON_ROCFFT, "pruned": _lib.SMI_POISSON_PRUNED}[backend]
+        return bool(_lib.lib.smi_poisson_supports(int(grid_size_z), int(grid_size_y), int(grid_size_x), int(nranks), code))
 
     def solve(self, solution_field, rhs_field):
         """-del^2(solution_field) = rhs_field, unbounded domain (:133-167)."""

@@ -74,7 +74,8 @@ for step in range(3):
         ref.compute_interaction_force_on_eul_and_lag_grid(cpu.eul_grid_forcing_field, cpu.velocity_field, pos,
                                                           np.zeros_like(pos))
         if rank == 0:
-            assert_close(interactor.global_lag_grid_forcing_field, ref.lag_forcing, np.float64, factor=1e7,
+            assert_close(interactor.global_lag_grid_forcing_field, ref.lag_forcing, np.float32, factor=1.0,  # f64 arrays interpolated from the f32 velocity
+                        
                          what=f"lag forcing step {step}")
     gpu.time_step(dt=dt, free_stream_velocity=fs)
     cpu.time_step(dt=dt, free_stream_velocity=fs)
@@ -83,8 +84,8 @@ for step in range(3):
     comm.gather_local_vector_field(got_w, gpu.vorticity_field)
     comm.gather_local_vector_field(got_u, gpu.velocity_field)
     if rank == 0:
-        assert_close(got_w, cpu.vorticity_field[inner], real_t, factor=2.0 + step, what=f"vorticity step {step}")
-        assert_close(got_u, cpu.velocity_field[inner], real_t, factor=4.0 + step, what=f"velocity step {step}")
+        assert_close(got_w, cpu.vorticity_field[inner], real_t, factor=1.0 + 0.5 * step, what=f"vorticity step {step}")
+        assert_close(got_u, cpu.velocity_field[inner], real_t, factor=1.0 + 0.5 * step, what=f"velocity step {step}")
 mv = gpu.get_max_vorticity()
 assert abs(float(mv) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(float(cpu.get_max_vorticity()))
 world.barrier()

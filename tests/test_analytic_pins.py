@@ -56,33 +56,34 @@ class _GpuOps:
         self.ctx = make_ctx(sopht_mpi_amd, shape, g, real_t)
         self.real_t = real_t
 
-    def _call(self, name, *a):
-        self.smi._lib.call(name, self.ctx.handle, *a)
+    def _call(self, name, *fields_and_scalars):
+        # the DeviceField arguments stay referenced until the call has returned and the result was downloaded
+        args = [a.ptr if hasattr(a, "ptr") else a for a in fields_and_scalars]
+        self.smi._lib.call(name, self.ctx.handle, *args)
 
     def cross(self, a, b):
-        out = self.ctx.field(3)
-        self._call("smi_cross_product", out.ptr, self.ctx.from_numpy(a).ptr, self.ctx.from_numpy(b).ptr)
+        out, da, db = self.ctx.field(3), self.ctx.from_numpy(a), self.ctx.from_numpy(b)
+        self._call("smi_cross_product", out, da, db)
         return out.get()
 
     def update_vorticity(self, w, f, p):
-        dw = self.ctx.from_numpy(w)
-        self._call("smi_update_vorticity_from_velocity_forcing", dw.ptr, self.ctx.from_numpy(f).ptr,
-                   float(self.real_t(p)))
+        dw, df = self.ctx.from_numpy(w), self.ctx.from_numpy(f)
+        self._call("smi_update_vorticity_from_velocity_forcing", dw, df, float(self.real_t(p)))
         return dw.get()
 
     def diffusion_flux(self, f, c):
-        out = self.ctx.field(3)
-        self._call("smi_diffusion_flux", out.ptr, self.ctx.from_numpy(f).ptr, float(self.real_t(c)), 3)
+        out, df = self.ctx.field(3), self.ctx.from_numpy(f)
+        self._call("smi_diffusion_flux", out, df, float(self.real_t(c)), 3)
         return out.get()
 
     def curl(self, f, p):
-        out = self.ctx.field(3)
-        self._call("smi_curl", out.ptr, self.ctx.from_numpy(f).ptr, float(self.real_t(p)))
+        out, df = self.ctx.field(3), self.ctx.from_numpy(f)
+        self._call("smi_curl", out, df, float(self.real_t(p)))
         return out.get()
 
     def divergence(self, f, inv_dx):
-        out = self.ctx.field()
-        self._call("smi_divergence", out.ptr, self.ctx.from_numpy(f).ptr, float(self.real_t(inv_dx)))
+        out, df = self.ctx.field(), self.ctx.from_numpy(f)
+        self._call("smi_divergence", out, df, float(self.real_t(inv_dx)))
         return out.get()
 
 

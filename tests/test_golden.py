@@ -27,7 +27,7 @@ def test_oracle_reproduces_golden(name):
             assert np.array_equal(got[k], want[k]), (name, k)
         else:
             # same code on the same seeds: only FFT library / BLAS differences may show
-            assert_close(got[k], want[k], np.float64, factor=100, what=f"{name}:{k}")
+            assert_close(got[k], want[k], np.float64, factor=25, what=f"{name}:{k}")
 
 
 @pytest.mark.gpu
@@ -38,7 +38,7 @@ def test_gpu_stencils_match_golden(smi, real_t):
     ctx = make_ctx(smi, gc.SHAPE, gc.G, real_t)
     call = smi._lib.call
     df, dh, out = ctx.from_numpy(f), ctx.from_numpy(h), ctx.field(3)
-    fac = 4.0  # inputs rounded to f32 move the f64 golden by a few ulp of the inputs
+    fac = 1.0  # inputs rounded to f32 move the f64 golden by a few ulp of the inputs
     call("smi_diffusion_flux", ctx.handle, out.ptr, df.ptr, 0.137, 3)
     assert_close(out.get(), want["diffusion_flux"], real_t, factor=fac, what="diffusion flux")
     call("smi_curl", ctx.handle, out.ptr, df.ptr, 0.5)
@@ -72,7 +72,7 @@ def test_gpu_poisson_matches_golden(smi, real_t, backend):
     solver.vector_field_solve(dsol, drhs)
     g = gc.G
     inner = (slice(None),) + (slice(g, -g),) * 3
-    assert_close(dsol.get()[inner], want[inner], real_t, factor=4.0, what="Poisson solution")
+    assert_close(dsol.get()[inner], want[inner], real_t, factor=2.0, what="Poisson solution")
 
 
 @pytest.mark.gpu
@@ -91,8 +91,8 @@ def test_gpu_flow_steps_match_golden(smi, real_t, fused):
         sim.time_step(dt=gc.FLOW_DT, free_stream_velocity=gc.FLOW_FREE_STREAM)
     g = gc.G
     inner = (slice(None),) + (slice(g, -g),) * 3
-    assert_close(sim.vorticity_field.get()[inner], want["vorticity"][inner], real_t, factor=4.0, what="vorticity")
-    assert_close(sim.velocity_field.get()[inner], want["velocity"][inner], real_t, factor=6.0, what="velocity")
+    assert_close(sim.vorticity_field.get()[inner], want["vorticity"][inner], real_t, factor=1.0, what="vorticity")
+    assert_close(sim.velocity_field.get()[inner], want["velocity"][inner], real_t, factor=1.0, what="velocity")
 
 
 @pytest.mark.gpu
@@ -114,10 +114,10 @@ def test_gpu_immersed_boundary_matches_golden(smi):
     comm.local_eulerian_grid_support_of_lagrangian_grid_kernel(dsup, didx, dpos)
     assert np.array_equal(didx.get(), want["nearest_index"])
     comm.interpolation_weights_kernel(dwts, dsup)
-    assert_close(dwts.get(), want["weights"], np.float64, factor=100, what="weights")
+    assert_close(dwts.get(), want["weights"], np.float64, factor=1, what="weights")
     dlag = ctx.zeros((3, m), np.float64)
     comm.eulerian_to_lagrangian_grid_interpolation_kernel(dlag, ctx.from_numpy(eul), dwts, didx)
-    assert_close(dlag.get(), want["interpolated"], np.float64, factor=1e3, what="E->L")
+    assert_close(dlag.get(), want["interpolated"], np.float64, factor=1, what="E->L")
     dfor = ctx.field(3)
     comm.lagrangian_to_eulerian_grid_interpolation_kernel(dfor, ctx.from_numpy(lag), dwts, didx)
-    assert_close(dfor.get(), want["spread"], np.float64, factor=1e3, what="L->E")
+    assert_close(dfor.get(), want["spread"], np.float64, factor=1, what="L->E")

@@ -49,13 +49,13 @@ def test_fft_mpi_3d_matches_scipy(smi, shape, real_t):
     want = scipy.fft.rfftn(field.astype(np.float64))
     got = fft.fourier_field_buffer.get()
     assert got.dtype == fft.complex_dtype
-    assert_close(got.view(real_t), want.astype(fft.complex_dtype).view(real_t), real_t, factor=4.0, what="rfftn")
+    assert_close(got.view(real_t), want.astype(fft.complex_dtype).view(real_t), real_t, factor=1.0, what="rfftn")
     # backward is normalised and must not disturb its input
     spectrum = want.astype(fft.complex_dtype)
     fft.fourier_field_buffer[...] = spectrum
     inv = fft.ctx.zeros(shape, real_t)
     fft.backward(fourier_field=fft.fourier_field_buffer, inv_fourier_field=inv)
-    assert_close(inv.get(), field, real_t, factor=4.0, what="irfftn")
+    assert_close(inv.get(), field, real_t, factor=2.0, what="irfftn")
     assert np.array_equal(fft.fourier_field_buffer.get(), spectrum), "backward overwrote its input"
 
 
@@ -69,10 +69,10 @@ def test_fft_mpi_2d_matches_scipy(smi, shape, real_t):
     fft.field_buffer[...] = field
     fft.forward(field=fft.field_buffer, fourier_field=fft.fourier_field_buffer)
     want = scipy.fft.rfftn(field.astype(np.float64)).astype(fft.complex_dtype)
-    assert_close(fft.fourier_field_buffer.get().view(real_t), want.view(real_t), real_t, factor=4.0, what="rfft2")
+    assert_close(fft.fourier_field_buffer.get().view(real_t), want.view(real_t), real_t, factor=1.0, what="rfft2")
     inv = fft.ctx.zeros(shape, real_t)
     fft.backward(fourier_field=fft.fourier_field_buffer, inv_fourier_field=inv)
-    assert_close(inv.get(), field, real_t, factor=4.0, what="irfft2")
+    assert_close(inv.get(), field, real_t, factor=2.0, what="irfft2")
 
 
 def test_fft_api_errors(smi):
@@ -164,11 +164,11 @@ def test_reference_solve_sequence_from_pieces(smi, real_t):
     comm.copy_from_doubled_domain(local_doubled_field=fft.field_buffer, local_field=dsol)
     want = np.zeros_like(rhs)
     oracle.solve(want, rhs, g)
-    assert_close(dsol.get(), want, real_t, factor=4.0, what="solve from pieces vs oracle")
+    assert_close(dsol.get(), want, real_t, factor=2.0, what="solve from pieces vs oracle")
     solver = UnboundedPoissonSolverMPI3D(*shape, mpi_construct=c, ghost_size=g, x_range=x_range, real_t=real_t)
     dsol2 = ctx.field()
     solver.solve(solution_field=dsol2, rhs_field=drhs)
-    assert_close(dsol.get(), dsol2.get(), real_t, factor=4.0, what="solve from pieces vs library solver")
+    assert_close(dsol.get(), dsol2.get(), real_t, factor=2.0, what="solve from pieces vs library solver")
 
 
 @pytest.mark.parametrize("real_t", PRECISIONS)
@@ -192,7 +192,7 @@ def test_advection_flux_eno3_3d(smi, shape, real_t):
     op(advection_flux=dflux, field=ctx.from_numpy(field), velocity=ctx.from_numpy(vel), inv_dx=inv_dx)
     want = flux0.copy()
     o3.advection_flux_eno3(want, field, vel, inv_dx, g)
-    assert_close(dflux.get(), want, real_t, factor=4.0, what="advection flux 3d")
+    assert_close(dflux.get(), want, real_t, factor=1.0, what="advection flux 3d")
     untouched = want == flux0
     assert np.array_equal(dflux.get()[untouched], flux0[untouched])
     with pytest.raises(ValueError):
@@ -224,7 +224,7 @@ def test_advection_flux_eno3_2d(smi, real_t):
     flux_op(advection_flux=dflux, field=dfield, velocity=dvel, inv_dx=-dt_by_dx)
     want_field, want_flux = field.copy(), np.zeros(pshape, dtype=real_t)
     o2.advection_timestep_eno3(want_field, want_flux, vel, dt_by_dx, g)
-    assert_close(dflux.get(), want_flux, real_t, factor=4.0, what="advection flux 2d")
+    assert_close(dflux.get(), want_flux, real_t, factor=1.0, what="advection flux 2d")
     # cells outside the update set keep what they held
     sentinel = rand_field(rng, pshape, real_t)
     dflux2 = ctx.from_numpy(sentinel)
@@ -236,4 +236,4 @@ def test_advection_flux_eno3_2d(smi, real_t):
     # and the timestep operator agrees with field + flux
     scratch = ctx.zeros(pshape, real_t)
     step_op(field=dfield, advection_flux=scratch, velocity=dvel, dt_by_dx=dt_by_dx)
-    assert_close(dfield.get(), want_field, real_t, factor=4.0, what="advection timestep 2d")
+    assert_close(dfield.get(), want_field, real_t, factor=1.0, what="advection timestep 2d")

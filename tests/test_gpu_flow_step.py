@@ -3,7 +3,7 @@ reference's own simulator API (operator-by-operator and fused), several steps in
 import numpy as np
 import pytest
 
-from helpers import assert_close
+from helpers import assert_close, assert_pointwise
 from oracle.flow_3d import FlowSimulator3D as OracleSim
 
 pytestmark = pytest.mark.gpu
@@ -34,31 +34,35 @@ def _pair(smi, n, flow_type, real_t, **kw):
     return gpu, cpu
 
 
-@pytest.mark.parametrize("backend", ["rocfft", "pruned"])
+NS_CASES = [
+    ((16, 16, 16), "navier_stokes", False, False),
+    ((16, 16, 32), "navier_stokes", True, False),
+    ((32, 32, 32), "navier_stokes_with_forcing", True, False),
+    ((16, 16, 16), "navier_stokes_with_forcing", True, True),
+]
+
+
+def _ns_params():
+    from sopht_mpi_amd._lib import lib
+
+    out = []
+    for backend, code in (("rocfft", 0), ("pruned", 1)):
+        for n, flow_type, free_stream, filt in NS_CASES:
+            marks = [] if lib.smi_poisson_supports(n[0], n[1], n[2], 1, code) else [
+                pytest.mark.skip(reason=f"smi_poisson_supports: no {backend} plan for grid {n}")]
+            out.append(pytest.param(n, flow_type, free_stream, filt, backend, marks=marks))
+    return out
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
-@pytest.mark.parametrize(
-    "n,flow_type,free_stream,filt",
-    [
-        ((16, 16, 16), "navier_stokes", False, False),
-        ((16, 16, 32), "navier_stokes", True, False),
-        ((32, 32, 32), "navier_stokes_with_forcing", True, False),
-        ((16, 16, 16), "navier_stokes_with_forcing", True, True),
-    ],
-)
+@pytest.mark.parametrize("n,flow_type,free_stream,filt,backend", _ns_params())
 def test_navier_stokes_steps(smi, n, flow_type, free_stream, filt, real_t, fused, backend):
-    from sopht_mpi_amd._lib import SophtMIError
-
     rng = np.random.default_rng(11)
     kw = dict(with_free_stream_flow=free_stream, filter_vorticity=filt)
     if filt:
         kw["filter_setting_dict"] = {"order": 1, "type": "multiplicative"}
-    try:
-        gpu, cpu = _pair(smi, n, flow_type, real_t, fused_step=fused, poisson_backend=backend, **kw)
-    except SophtMIError as exc:
-        if "not available" in str(exc) or "power of two" in str(exc):
-            pytest.skip(str(exc))
-        raise
+    gpu, cpu = _pair(smi, n, flow_type, real_t, fused_step=fused, poisson_backend=backend, **kw)
     assert gpu.unbounded_poisson_solver.backend == backend
     w0 = _blob_vorticity(cpu.vorticity_field.shape[1:], cpu.position_field, rng, real_t)
     gpu.vorticity_field[...] = w0
@@ -66,7 +70,7 @@ def test_navier_stokes_steps(smi, n, flow_type, free_stream, filt, real_t, fused
     fs = np.array([1.0, 0.5, -0.25])
     gpu.compute_flow_velocity(free_stream_velocity=fs)
     cpu.compute_flow_velocity(free_stream_velocity=fs)
-    assert_close(gpu.velocity_field.get(), cpu.velocity_field, real_t, factor=3.0, what="initial velocity")
+    assert_close(gpu.velocity_field.get(), cpu.velocity_field, real_t, factor=2.0, what="initial velocity")
     for step in range(3):
         dt_gpu = gpu.compute_stable_timestep(dt_prefac=0.5)
         dt_cpu = cpu.compute_stable_timestep(dt_prefac=0.5)
@@ -79,12 +83,13 @@ def test_navier_stokes_steps(smi, n, flow_type, free_stream, filt, real_t, fused
         cpu.time_step(dt=dt_cpu, free_stream_velocity=fs)
         g = gpu.ghost_size
         inner = (slice(None),) + (slice(g, -g),) * 3
-        # north-star bar: vorticity to 1e-5 (relative to its maximum); errors of three steps add up
-        assert_close(gpu.vorticity_field.get()[inner], cpu.vorticity_field[inner], real_t, factor=1.0 + step,
+        # vorticity to 2e-6 of its maximum (a fifth of the north-star 1e-5) and pointwise to rtol 1e-5; errors of the steps add up
+        assert_close(gpu.vorticity_field.get()[inner], cpu.vorticity_field[inner], real_t, factor=1.0 + 0.5 * step,
                      what=f"vorticity step {step}")
-        assert_close(gpu.velocity_field.get()[inner], cpu.velocity_field[inner], real_t, factor=3.0 + step,
+        assert_pointwise(gpu.vorticity_field.get()[inner], cpu.vorticity_field[inner], real_t, what=f"vorticity step {step}")
+        assert_close(gpu.velocity_field.get()[inner], cpu.velocity_field[inner], real_t, factor=2.0 + 0.5 * step,
                      what=f"velocity step {step}")
-        assert_close(gpu.vorticity_field.get(), cpu.vorticity_field, real_t, factor=2.0 + step,
+        assert_close(gpu.vorticity_field.get(), cpu.vorticity_field, real_t, factor=1.0 + 0.5 * step,
                      what=f"vorticity incl. ghosts step {step}")
     assert gpu.time == cpu.time
     if flow_type == "navier_stokes_with_forcing":
@@ -115,7 +120,7 @@ def test_passive_transport_steps(smi, flow_type, real_t):
         assert abs(gpu.compute_stable_timestep(dt_prefac=0.5) - dt) <= 1e-5 * dt
         gpu.time_step(dt=dt)
         cpu.time_step(dt=dt)
-        assert_close(getattr(gpu, name).get(), getattr(cpu, name), real_t, factor=2.0 + step,
+        assert_close(getattr(gpu, name).get(), getattr(cpu, name), real_t, factor=1.0 + 0.5 * step,
                      what=f"{flow_type} step {step}")
     assert gpu.time == cpu.time
 

@@ -61,13 +61,13 @@ def test_poisson_back_ends_agree_and_solve_is_linear(smi, sim):
     rocfft.vector_field_solve(s2, d1)
     a = s1.get()
     inner = (slice(None),) + (slice(G, -G),) * 3
-    assert_close(a[inner], s2.get()[inner], real_t, factor=2.0, what="pruned vs rocFFT at 512^3")
+    assert_close(a[inner], s2.get()[inner], real_t, factor=3.0, what="pruned vs rocFFT at 512^3")
     # linearity: solve(2 f1 - 3 f2) = 2 solve(f1) - 3 solve(f2)
     pruned.vector_field_solve(s2, d2)
     b = s2.get()
     smi._lib.call("smi_elementwise_saxpby", ctx.handle, d1.ptr, d1.ptr, 2.0, d2.ptr, -3.0, 3)
     pruned.vector_field_solve(s3, d1)
-    assert_close(s3.get()[inner], (2 * a - 3 * b)[inner], real_t, factor=4.0, what="linearity")
+    assert_close(s3.get()[inner], (2 * a - 3 * b)[inner], real_t, factor=2.0, what="linearity")
 
 
 def test_poisson_gaussian_blob_closed_form(smi, sim):
@@ -119,7 +119,7 @@ def test_velocity_is_divergence_free_and_fused_step_matches_sequence(smi, sim):
         sim.time_step(dt=dt)
         seq.time_step(dt=dt)
     inner = (slice(None),) + (slice(G, -G),) * 3
-    assert_close(sim.vorticity_field.get()[inner], seq.vorticity_field.get()[inner], real_t, factor=2.0,
+    assert_close(sim.vorticity_field.get()[inner], seq.vorticity_field.get()[inner], real_t, factor=1.0,
                  what="fused vs sequenced vorticity")
-    assert_close(sim.velocity_field.get()[inner], seq.velocity_field.get()[inner], real_t, factor=4.0,
+    assert_close(sim.velocity_field.get()[inner], seq.velocity_field.get()[inner], real_t, factor=1.0,
                  what="fused vs sequenced velocity")

@@ -44,13 +44,13 @@ def test_ib_operators(smi, n, real_t, kernel_type):
     w_idx = np.empty((3, m), dtype=np.int64)
     oib.local_eulerian_grid_support_of_lagrangian_grid(w_sup, w_idx, pos, dx, shift, 2, np.zeros(3, dtype=np.int64) - g)
     assert np.array_equal(didx.get(), w_idx), "nearest index must be bit exact"
-    assert_close(dsup.get(), w_sup, np.float64, scale=float(dx), factor=10, what="support")
+    assert_close(dsup.get(), w_sup, np.float64, scale=float(dx), factor=8, what="support")
     comm.interpolation_weights_kernel(dwts, dsup)
     w_wts = np.empty((4, 4, 4, m))
     (oib.cosine_interpolation_weights if kernel_type == "cosine" else oib.peskin_interpolation_weights)(
         w_wts, w_sup, dx, real_t)
-    assert_close(dwts.get(), w_wts, np.float64, factor=100, what="weights")
-    assert_close(dsup.get(), w_sup, np.float64, factor=10, what="support after weights (mutated in place)")
+    assert_close(dwts.get(), w_wts, np.float64, factor=8, what="weights")
+    assert_close(dsup.get(), w_sup, np.float64, factor=4, what="support after weights (mutated in place)")
     # partition of unity: interpolating the constant 2.0 returns 2.0
     # (tests/.../test_eulerian_lagrangian_grid_communicator_mpi_3d.py:114-149)
     const = ctx.from_numpy(np.full((3,) + ctx.padded_shape, 2.0, dtype=real_t))
@@ -63,7 +63,7 @@ def test_ib_operators(smi, n, real_t, kernel_type):
     comm.eulerian_to_lagrangian_grid_interpolation_kernel(dlag, deul, dwts, didx)
     w_lag = np.zeros((3, m))
     oib.eulerian_to_lagrangian_grid_interpolation(w_lag, eul, w_wts, w_idx, dx)
-    assert_close(dlag.get(), w_lag, np.float64, factor=1e4, what="E->L")
+    assert_close(dlag.get(), w_lag, np.float64, factor=8, what="E->L")
     # L -> E with overlapping windows (+ single-rank ghost sum = ghost clearing)
     lag = rng.standard_normal((3, m))
     dl = ctx.from_numpy(lag)
@@ -72,7 +72,7 @@ def test_ib_operators(smi, n, real_t, kernel_type):
     w_for = eul.copy()
     oib.lagrangian_to_eulerian_grid_interpolation(w_for, lag, w_wts, w_idx)
     oib.clear_ghost_cells(w_for, g)
-    assert_close(dfor.get(), w_for, real_t, factor=4, what="L->E")
+    assert_close(dfor.get(), w_for, real_t, factor=5, what="L->E")
 
 
 @pytest.mark.parametrize("kernel_type", ["cosine", "peskin"])
@@ -100,14 +100,14 @@ def test_virtual_boundary_forcing(smi, real_t, kernel_type):
         gpu.compute_interaction_forcing(dforce, du, pos_t, vel)
         wforce = np.zeros_like(u)
         cpu.compute_interaction_force_on_eul_and_lag_grid(wforce, u, pos_t, vel)
-        assert_close(gpu.local_lag_grid_flow_velocity_field.get(), cpu.lag_flow_velocity, np.float64, factor=1e4,
+        assert_close(gpu.local_lag_grid_flow_velocity_field.get(), cpu.lag_flow_velocity, np.float64, factor=8,
                      what="flow velocity on lag grid")
-        assert_close(gpu.global_lag_grid_forcing_field, cpu.lag_forcing, np.float64, factor=1e4, what="lag forcing")
-        assert_close(dforce.get(), wforce, real_t, factor=4, what="eul forcing")
+        assert_close(gpu.global_lag_grid_forcing_field, cpu.lag_forcing, np.float64, factor=1, what="lag forcing")
+        assert_close(dforce.get(), wforce, real_t, factor=8, what="eul forcing")
         gpu.time_step(0.01)
         cpu.time_step(0.01)
         assert_close(gpu.local_lag_grid_position_mismatch_field.get(), cpu.lag_position_mismatch, np.float64,
-                     factor=1e4, what="position mismatch")
+                     factor=1, what="position mismatch")
     assert gpu.time == pytest.approx(cpu.time)
 
 
