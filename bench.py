@@ -8,6 +8,8 @@ torch.distributed.run, one rank per GPU): the same 512^3 grid cut into N z-slabs
 scaling: total work fixed).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -30,7 +32,40 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 ALG_BYTES_PER_POINT_STEP = 1692.0
 MIN_BYTES_PER_POINT_STEP = 660.0
 IMPL_BYTES_PER_POINT_STEP = 408.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_counters_512cubed_v7.json")
+# rocprofv3 --pmc counters of every hot kernel (tools/pmc_bench.sh + tools/make_counters_json.py); they are not
+# measured inside this run: the file records the hash of the library sources it was collected on, and its figures
+# are withheld when that differs from the sources in this tree
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_counters_512cubed.json")
+
+
+def lib_source_hash():
+    """sha256 over the sources libsophtmi.so is built from (csrc/*.hip, csrc/*.h, include/sophtmi.h, Makefile)."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "sopht-mpi_amd", "csrc", "*.hip"))
+                   + glob.glob(os.path.join(ROOT, "sopht-mpi_amd", "csrc", "*.h")))
+    files += [os.path.join(ROOT, "include", "sophtmi.h"), os.path.join(ROOT, "Makefile")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_counters(grid, n_gpus, dtype):
+    """(record, source string) of the committed counter passes when they describe this configuration AND this
+    build of the library; (None, reason) otherwise."""
+    rel = os.path.relpath(TRAFFIC_FILE, ROOT)
+    try:
+        with open(TRAFFIC_FILE) as f:
+            rec = json.load(f)
+    except OSError:
+        return None, f"{rel} missing"
+    if n_gpus != 1 or list(rec.get("grid", [])) != [grid] * 3 or rec.get("dtype") != dtype:
+        return None, f"{rel} covers 1 GPU, grid {rec.get('grid')}, {rec.get('dtype')}: not this run"
+    have, want = rec.get("lib_source_sha256"), lib_source_hash()
+    if have != want:
+        return None, f"{rel} was collected on library sources {have}, this tree is {want}: stale, withheld"
+    return rec, f"{rel} (separate rocprofv3 --pmc passes on library sources {have}; not measured in this run)"
 
 
 def synthetic_vorticity(position_field, real_t, seed=0, nblobs=8, sigma=0.05):
@@ -54,57 +89,29 @@ def synthetic_vorticity(position_field, real_t, seed=0, nblobs=8, sigma=0.05):
     return out
 
 
-def measured_traffic(slot, grid, n_gpus):
-    """HBM bytes per launch of a profiler slot from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this benchmark), or None when
-    the passes do not cover this configuration."""
-    try:
-        with open(TRAFFIC_FILE) as f:
-            rec = json.load(f)
-    except OSError:
-        return None
-    if n_gpus != 1 or list(rec.get("grid", [])) != [grid] * 3:
-        return None
-    k = rec["kernels"].get(slot)
-    return k.get("hbm_bytes") if k else None
-
-
-def measured_valu_floor_ms(slot, grid, n_gpus):
-    """Time the wave-level VALU instructions of one launch need at the chip's scalar-f32 issue
-    rate (packed math is compiled out), from the same committed counter passes; None when
-    they do not cover this configuration."""
-    try:
-        with open(TRAFFIC_FILE) as f:
-            rec = json.load(f)
-    except OSError:
-        return None
-    if n_gpus != 1 or list(rec.get("grid", [])) != [grid] * 3:
-        return None
-    k = rec["kernels"].get(slot)
-    return k.get("valu_floor_ms") if k else None
-
-
-def roofline_from_profile(prof, grid, n_gpus):
+def roofline_from_profile(prof, counters, counters_source):
     """Roofline entry for the dominant kernel: the profiler slot with the largest total time
     inside the timed region (HIP events recorded on the library's own stream around every
     launch).  achieved = algorithmic bytes per launch / average launch duration."""
-    if not prof:
+    kernels = {k: v for k, v in prof.items() if k != "flow_step"}
+    if not kernels:
         return None
-    name, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    name, rec = max(kernels.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = rec["ms"] / rec["launches"]
     achieved = rec["alg_bytes"] / rec["launches"] / (avg_ms * 1e-3) / 1e9
+    k = (counters or {}).get("kernels", {}).get(name, {})
     out = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(name, grid, n_gpus),
-           "avg_launch_ms": avg_ms, "alg_bytes_per_launch": rec["alg_bytes"] / rec["launches"]}
-    floor = measured_valu_floor_ms(name, grid, n_gpus)
-    if floor is not None:
+           "frac": achieved / HBM_PEAK_GBS, "traffic": k.get("hbm_bytes"), "traffic_source": counters_source,
+           "avg_launch_ms": avg_ms, "median_launch_ms": float(np.median(rec["samples_ms"])),
+           "alg_bytes_per_launch": rec["alg_bytes"] / rec["launches"]}
+    if k.get("valu_floor_ms") is not None:
         # second ceiling of the same kernel: its VALU instruction stream at the measured issue rate
-        out["valu_issue_floor_ms"] = floor
-        out["valu_issue_frac"] = floor / avg_ms
+        out["valu_issue_floor_ms"] = k["valu_floor_ms"]
+        out["valu_issue_frac"] = k["valu_floor_ms"] / avg_ms
     return out
 
 
-def cpu_baseline(grid, steps):
+def cpu_baseline(grid, steps, warmup):
     """The oracle (CPU restatement, not sopht-mpi itself) timed on this box's host cores."""
     from oracle import poisson as opoisson
     from oracle.flow_3d import FlowSimulator3D
@@ -115,17 +122,22 @@ def cpu_baseline(grid, steps):
     sim.vorticity_field[...] = synthetic_vorticity(sim.position_field, np.float32)
     sim.compute_flow_velocity()
     dt = float(sim.compute_stable_timestep())
-    sim.time_step(dt)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(warmup):
         sim.time_step(dt)
-    el = time.perf_counter() - t0
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        sim.time_step(dt)
+        times.append(time.perf_counter() - t0)
     return {
-        "value": grid**3 * steps / el,
+        "value": grid**3 / float(np.median(times)),
         "unit": "grid-point-updates/s",
         "cores": workers,
         "kind": "port",
-        "sample": f"{steps} navier_stokes steps on a {grid}^3 grid (numpy stencils on 1 core, scipy.fft on "
+        "ms_per_step_median": 1e3 * float(np.median(times)),
+        "ms_per_step_mean": 1e3 * float(np.mean(times)),
+        "sample": f"median of {steps} navier_stokes steps after {warmup} warm-up steps on a {grid}^3 grid, same "
+                  f"seeded vorticity and dt rule as the GPU run (numpy stencils on 1 core, scipy.fft on "
                   f"{workers} threads); restatement of the reference algorithm, not sopht-mpi itself",
     }
 
@@ -139,7 +151,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--poisson", default=None, choices=[None, "rocfft", "pruned"])
     ap.add_argument("--cpu-grid", type=int, default=256)
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -157,6 +170,9 @@ def main():
     sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=1e-3,
                                    flow_type="navier_stokes", real_t=real_t, ghost_size=2, penalty_zone_width=2,
                                    poisson_backend=args.poisson)
+    if args.gpus > 1 and sim.ctx.transport != "rccl":
+        raise SystemExit(f"bench: {args.gpus} ranks but the transport is {sim.ctx.transport!r}, not rccl; "
+                         "refusing to report a multi-GPU figure that did not go over RCCL")
     sim.vorticity_field[...] = synthetic_vorticity(sim.position_field, real_t)
     sim.compute_flow_velocity(free_stream_velocity=None)
     dt = float(sim.compute_stable_timestep())  # CFL 0.1, fixed over the timed region
@@ -184,6 +200,36 @@ def main():
         return
     ms = 1e3 * elapsed / args.steps
     value = n**3 * args.steps / elapsed
+    counters, counters_source = load_counters(n, args.gpus, args.dtype)
+    per_gpu = value / args.gpus / 1e9 / HBM_PEAK_GBS   # bytes per point -> fraction of one GPU's HBM peak
+    step_samples = prof.get("flow_step", {}).get("samples_ms", [])
+    kernels = {k: v for k, v in prof.items() if k != "flow_step"}
+    config = {
+        "workload": f"3D {n}^3 navier_stokes flow step (rotational advection + diffusion + penalise + "
+                    "3 unbounded Poisson solves + curl), ghost 2, seeded Gaussian-blob vorticity",
+        "grid": [n, n, n],
+        "partition": "1 GPU" if args.gpus == 1 else f"{args.gpus} z-slabs",
+        "transport": sim.ctx.transport,
+        "rccl_ranks": args.gpus if sim.ctx.transport == "rccl" else 0,
+        "poisson_backend": sim.unbounded_poisson_solver.backend,
+        # fraction of the HBM peak the step reaches, on the bytes this implementation moves by design
+        # (408 B per grid point and step in f32: advect 9 S + diffuse 6 S + 3 x Poisson 27 S + curl 6 S)
+        "step_bytes_model": f"implementation, {IMPL_BYTES_PER_POINT_STEP * (1 if args.dtype == 'f32' else 2):.0f} B per "
+                            "grid point per step",
+        "step_hbm_frac": IMPL_BYTES_PER_POINT_STEP * (1 if args.dtype == "f32" else 2) * per_gpu,
+        # the same with the HBM bytes the kernels were measured to move (sum over the counter file), when current
+        "step_hbm_frac_measured": None,
+        # two byte models of the survey, for reference: the reference's operator sequence with padded FFTs
+        # (the implementation skips most of that work, so this exceeds 1), and its pruned lower bound
+        "step_hbm_frac_model_reference_sequence_1692B": ALG_BYTES_PER_POINT_STEP * per_gpu,
+        "step_hbm_frac_model_pruned_lower_bound_660B": MIN_BYTES_PER_POINT_STEP * per_gpu,
+    }
+    if counters:
+        launches = {k: v["launches"] / args.steps for k, v in kernels.items()}
+        measured = sum(counters["kernels"][k]["hbm_bytes"] * launches[k] for k in launches
+                       if k in counters["kernels"] and "hbm_bytes" in counters["kernels"][k])
+        config["step_hbm_bytes_measured"] = measured
+        config["step_hbm_frac_measured"] = measured / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out = {
         "metric": "grid-point-updates/sec per flow step (512^3 3D)",
         "value": value,
@@ -192,29 +238,22 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms,
+        "ms_per_step_median_device": float(np.median(step_samples)) if step_samples else None,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {
-            "workload": f"3D {n}^3 navier_stokes flow step (rotational advection + diffusion + penalise + "
-                        "3 unbounded Poisson solves + curl), ghost 2, seeded Gaussian-blob vorticity",
-            "grid": [n, n, n],
-            "partition": "1 GPU" if args.gpus == 1 else f"{args.gpus} z-slabs, transport {sim.ctx.transport}",
-            "poisson_backend": sim.unbounded_poisson_solver.backend,
-            "step_bytes_model": "lower bound, 660 B per grid point per step",
-            "step_hbm_frac": MIN_BYTES_PER_POINT_STEP * value / args.gpus / 1e9 / HBM_PEAK_GBS,
-            "step_hbm_frac_reference_sequence_model": ALG_BYTES_PER_POINT_STEP * value / args.gpus / 1e9 / HBM_PEAK_GBS,
-            "step_hbm_frac_implementation_bytes": IMPL_BYTES_PER_POINT_STEP * value / args.gpus / 1e9 / HBM_PEAK_GBS,
-        },
+        "config": config,
     }
-    out["roofline"] = roofline_from_profile(prof, n, args.gpus)
+    out["roofline"] = roofline_from_profile(prof, counters, counters_source)
     out["kernels"] = {k: {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"],
+                          "median_ms": float(np.median(v["samples_ms"])) if v["samples_ms"] else None,
                           "alg_GBps": v["alg_bytes"] / v["ms"] / 1e6 if v["ms"] > 0 else None}
-                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+                      for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+    out["lib_source_sha256"] = lib_source_hash()
     if args.gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_steps, args.cpu_warmup)
     print(json.dumps(out))
 
 

@@ -85,6 +85,9 @@ int smi_prof_reset(smi_ctx* ctx);
 int smi_prof_num_slots(void);
 int smi_prof_get(smi_ctx* ctx, int slot, char* name64, int64_t* launches, double* total_ms,
                  double* alg_bytes);
+/* the individual durations (ms) behind a slot's total, in launch order, at most `capacity` (the library keeps the
+ * first 4096 per slot since smi_prof_reset); the slot "flow_step" brackets each whole smi_flow_step_ns3d */
+int smi_prof_get_samples(smi_ctx* ctx, int slot, double* out_ms, int capacity, int* count);
 
 /* ---- memory ---------------------------------------------------------------- */
 int smi_malloc(smi_ctx* ctx, size_t bytes, void** dptr);

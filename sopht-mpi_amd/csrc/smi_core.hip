@@ -483,7 +483,7 @@ static const char* kSlotNames[PROF_NUM_SLOTS] = {
     "cross_product", "curl_update", "diffusion_flux", "elementwise_sum", "laplacian_filter", "penalise",
     "curl", "add_set_fixed", "poisson_pad", "poisson_rocfft_fwd", "poisson_multiply", "poisson_rocfft_inv",
     "poisson_extract", "fft_x_fwd", "fft_y_fwd", "fft_z_conv", "fft_y_inv", "fft_x_inv", "transpose", "halo",
-    "ib_forcing", "ib_spread", "fused_advect", "fused_diffuse", "advection_flux"};
+    "ib_forcing", "ib_spread", "fused_advect", "fused_diffuse", "advection_flux", "flow_step"};
 
 const char* smi_prof_slot_name(int slot) { return slot >= 0 && slot < PROF_NUM_SLOTS ? kSlotNames[slot] : "?"; }
 
@@ -523,6 +523,7 @@ static int prof_resolve(smi_ctx* c) {
       p->launches[r.slot] += 1;
       p->total_ms[r.slot] += ms;
       p->bytes[r.slot] += r.bytes;
+      if (p->samples[r.slot].size() < kProfMaxSamples) p->samples[r.slot].push_back(ms);
     }
     p->pool.push_back(r.a);
     p->pool.push_back(r.b);
@@ -547,11 +548,25 @@ extern "C" int smi_prof_reset(smi_ctx* c) {
     c->prof->launches[i] = 0;
     c->prof->total_ms[i] = 0;
     c->prof->bytes[i] = 0;
+    c->prof->samples[i].clear();
   }
   return 0;
 }
 
 extern "C" int smi_prof_num_slots(void) { return PROF_NUM_SLOTS; }
+
+extern "C" int smi_prof_get_samples(smi_ctx* c, int slot, double* out_ms, int capacity, int* count) {
+  SMI_REQUIRE(c && slot >= 0 && slot < PROF_NUM_SLOTS && count && capacity >= 0 && (out_ms || capacity == 0),
+              "smi_prof_get_samples: bad argument");
+  *count = 0;
+  if (!c->prof) return 0;
+  SMI_CHECK(prof_resolve(c));
+  const std::vector<float>& s = c->prof->samples[slot];
+  const int n = (int)s.size() < capacity ? (int)s.size() : capacity;
+  for (int i = 0; i < n; ++i) out_ms[i] = s[i];
+  *count = n;
+  return 0;
+}
 
 extern "C" int smi_prof_get(smi_ctx* c, int slot, char* name64, int64_t* launches, double* total_ms,
                             double* alg_bytes) {

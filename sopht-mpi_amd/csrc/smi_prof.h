@@ -32,6 +32,7 @@ enum SmiProfSlot {
   PROF_FUSED_ADVECT,
   PROF_FUSED_DIFFUSE,
   PROF_ADVECTION,
+  PROF_STEP,  // one whole smi_flow_step_ns3d (brackets the kernel slots above)
   PROF_NUM_SLOTS
 };
 
@@ -48,7 +49,10 @@ struct SmiProf {
   long long launches[PROF_NUM_SLOTS] = {};
   double total_ms[PROF_NUM_SLOTS] = {};
   double bytes[PROF_NUM_SLOTS] = {};
+  // individual durations (ms) of the first kProfMaxSamples scopes of each slot since the last reset
+  std::vector<float> samples[PROF_NUM_SLOTS];
 };
+constexpr size_t kProfMaxSamples = 4096;
 
 const char* smi_prof_slot_name(int slot);
 // bytes of one interior scalar field (the unit S of the algorithmic byte counts)

@@ -1,6 +1,7 @@
 // One Navier-Stokes flow step sequenced inside the library (flow_simulators_mpi_3d.py:395-424),
 // so that the host pays one call per step instead of one per operator.
 #include "smi_common.h"
+#include "smi_prof.h"
 
 static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
                           void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu, double dx,
@@ -19,6 +20,7 @@ extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, v
   const int saved = c->halo_depth;
   const bool shallow = filter_order == 0 || (filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE);
   if (shallow) c->halo_depth = 1;
+  SmiProfScope prof(c, PROF_STEP, 0.0);
   const int rc = flow_step_body(c, p, vorticity, velocity, stream_func, buffer_vector, buffer_scalar, forcing, dt, nu,
                                 dx, penalty_width, fac_lo, fac_hi, free_stream, filter_order, filter_type);
   c->halo_depth = saved;

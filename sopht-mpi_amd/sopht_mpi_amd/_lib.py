@@ -99,6 +99,7 @@ SIGNATURES = {
     "smi_prof_enable": [_p, _i],
     "smi_prof_reset": [_p],
     "smi_prof_get": [_p, _i, C.c_char_p, C.POINTER(C.c_int64), _dp, _dp],
+    "smi_prof_get_samples": [_p, _i, _dp, _i, C.POINTER(C.c_int)],
     "smi2d_diffusion_flux": [_p, _p, _p, _d],
     "smi2d_diffusion_timestep": [_p, _p, _p, _d],
     "smi2d_advection_timestep_eno3": [_p, _p, _p, _p, _d],
@@ -173,5 +174,9 @@ def prof_collect(ctx):
         n, ms, by = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
         call("smi_prof_get", ctx.handle, slot, name, C.byref(n), C.byref(ms), C.byref(by))
         if n.value:
-            out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "alg_bytes": by.value}
+            cap = min(int(n.value), 4096)
+            buf, cnt = (C.c_double * cap)(), C.c_int(0)
+            call("smi_prof_get_samples", ctx.handle, slot, buf, cap, C.byref(cnt))
+            out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "alg_bytes": by.value,
+                                        "samples_ms": list(buf[: cnt.value])}
     return out

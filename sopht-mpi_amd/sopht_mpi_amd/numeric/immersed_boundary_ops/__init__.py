@@ -231,22 +231,38 @@ class VirtualBoundaryForcingMPI:
     def update_buffers(self, global_lag_grid_position_field):
         """:238-276: re-map nodes to slabs; re-scatter the mismatch state when ownership changed."""
         comm = self.mpi_lagrangian_field_communicator
-        old_address = comm.rank_address.copy()
-        local_pm = self.local_lag_grid_position_mismatch_field.get()
-        local_vm = self.local_lag_grid_velocity_mismatch_field.get()
-        comm.gather_local_field(self.global_lag_grid_position_mismatch_field, local_pm)
-        comm.gather_local_field(self.global_lag_grid_velocity_mismatch_field, local_vm)
-        comm.map_lagrangian_nodes_based_on_position(global_lag_grid_position_field)
-        changed = not np.array_equal(old_address, comm.rank_address)
-        if changed:
-            self.local_num_lag_nodes = comm.local_num_lag_nodes
-            self._init_local_buffers(self.local_num_lag_nodes)
-            pm = np.zeros((self.grid_dim, self.local_num_lag_nodes))
-            vm = np.zeros_like(pm)
-            comm.scatter_global_field(pm, self.global_lag_grid_position_mismatch_field)
-            comm.scatter_global_field(vm, self.global_lag_grid_velocity_mismatch_field)
-            self.local_lag_grid_position_mismatch_field.set(pm)
-            self.local_lag_grid_velocity_mismatch_field.set(vm)
+        # The owner map first (host arithmetic on the master rank and M int32 on the wire).  The mismatch state
+        # leaves the device, travels to the master and back out only when a node has changed slabs; between such
+        # events (most calls: a body moves a fraction of a cell per step, and the interpolation runs once per
+        # sub-step of the body's own integrator) the reference's per-call gather of both fields is skipped, and
+        # the global mismatch arrays are brought up to date on demand (sync_global_mismatch_fields).
+        new_address = comm.owner_ranks_of(global_lag_grid_position_field)
+        if np.array_equal(new_address, comm.rank_address):
+            return
+        self.sync_global_mismatch_fields()   # with the ownership the local arrays were laid out for
+        comm.adopt_owner_ranks(new_address)
+        self.local_num_lag_nodes = comm.local_num_lag_nodes
+        self._init_local_buffers(self.local_num_lag_nodes)
+        pm = np.zeros((self.grid_dim, self.local_num_lag_nodes))
+        vm = np.zeros_like(pm)
+        comm.scatter_global_field(pm, self.global_lag_grid_position_mismatch_field)
+        comm.scatter_global_field(vm, self.global_lag_grid_velocity_mismatch_field)
+        self.local_lag_grid_position_mismatch_field.set(pm)
+        self.local_lag_grid_velocity_mismatch_field.set(vm)
+
+    def sync_global_mismatch_fields(self):
+        """Gather the device-resident mismatch state of every slab into ``global_lag_grid_position_mismatch_field``
+        and ``global_lag_grid_velocity_mismatch_field`` on the master rank (:243-251 does this on every call;
+        here it happens when ownership changes, and whenever a caller asks, e.g. before writing a restart)."""
+        if self.assume_data_locality or self.mpi_construct.size == 1:
+            self.global_lag_grid_position_mismatch_field[...] = self.local_lag_grid_position_mismatch_field.get()
+            self.global_lag_grid_velocity_mismatch_field[...] = self.local_lag_grid_velocity_mismatch_field.get()
+            return
+        comm = self.mpi_lagrangian_field_communicator
+        comm.gather_local_field(self.global_lag_grid_position_mismatch_field,
+                                self.local_lag_grid_position_mismatch_field.get())
+        comm.gather_local_field(self.global_lag_grid_velocity_mismatch_field,
+                                self.local_lag_grid_velocity_mismatch_field.get())
 
     # ---------------------------------------------------------------- interaction
     def _upload_lagrangian_state(self, global_lag_grid_position_field, global_lag_grid_velocity_field):

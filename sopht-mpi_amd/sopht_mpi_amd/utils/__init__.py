@@ -103,15 +103,21 @@ class MPIConstruct3D:
                     # every rank must end up on the same transport: agree on the outcome
                     try:
                         ctx.init_rccl()
-                        ok = 1.0
+                        ok, why = 1.0, ""
                     except _lib.SophtMIError as exc:
                         logger.error(f"rank {self.rank}: RCCL initialisation failed ({exc})")
-                        ok = 0.0
+                        ok, why = 0.0, str(exc)
                     if self.world.allreduce(ok, "min") < 1.0:
-                        logger.error("falling back to the host-staged transport on all ranks")
-                        ctx.init_host_staged()
-                else:
+                        # never silently: a run that was asked to go over RCCL and cannot must not carry on over
+                        # host memory and report figures as if it had (SOPHT_MI_TRANSPORT=host asks for that)
+                        raise RuntimeError(
+                            "RCCL initialisation failed on at least one rank" + (f" (this rank: {why})" if why else "")
+                            + "; set SOPHT_MI_TRANSPORT=host to run over the host-staged transport instead"
+                        )
+                elif mode == "host":
                     ctx.init_host_staged()
+                else:
+                    raise ValueError(f"SOPHT_MI_TRANSPORT={mode!r}: expected 'rccl' or 'host'")
             self._contexts[ghost_size] = ctx
         return ctx
 
@@ -153,22 +159,36 @@ class MPIFieldCommunicator3D:
         lz = self.mpi_construct.local_grid_size[0]
         return slice(rank * lz, (rank + 1) * lz)
 
+    def _slab_shape(self):
+        return tuple(int(n) for n in self.mpi_construct.local_grid_size)
+
     def scatter_global_scalar_field(self, local_field, global_field):
-        world = self.mpi_construct.world
-        data = world.bcast_object(global_field, root=self.master_rank) if world.size > 1 else global_field
+        """Each rank receives its own slab from the master, point to point (:1192-1247)."""
+        world, me = self.mpi_construct.world, self.mpi_construct.rank
+        dtype = np.dtype(local_field.dtype)
+        if me == self.master_rank:
+            glob = np.asarray(global_field, dtype=dtype)
+            mine = glob[self._slab(me)]
+            world.sendrecv({r: np.ascontiguousarray(glob[self._slab(r)]) for r in range(world.size) if r != me}, {})
+        else:
+            mine = np.empty(self._slab_shape(), dtype=dtype)
+            world.sendrecv({}, {self.master_rank: mine})
         host = local_field.get()
-        host[self.inner_idx] = np.asarray(data)[self._slab(self.mpi_construct.rank)]
+        host[self.inner_idx] = mine
         local_field.set(host)
 
     def gather_local_scalar_field(self, global_field, local_field):
-        world = self.mpi_construct.world
-        mine = local_field.get()[self.inner_idx]
-        if world.size == 1:
-            global_field[...] = mine
-            return
-        parts = [world.bcast_object(mine if world.rank == r else None, root=r) for r in range(world.size)]
-        if world.rank == self.master_rank:
-            global_field[...] = np.concatenate(parts, axis=0)
+        """Each rank sends its slab to the master, point to point (:1249-1306)."""
+        world, me = self.mpi_construct.world, self.mpi_construct.rank
+        mine = np.ascontiguousarray(local_field.get()[self.inner_idx])
+        if me == self.master_rank:
+            parts = {r: np.empty(self._slab_shape(), dtype=mine.dtype) for r in range(world.size) if r != me}
+            world.sendrecv({}, parts)
+            parts[me] = mine
+            for r, part in parts.items():
+                global_field[self._slab(r)] = part
+        else:
+            world.sendrecv({self.master_rank: mine}, {})
 
     def scatter_global_vector_field(self, local_vector_field, global_vector_field):
         for c in range(3):
@@ -209,7 +229,10 @@ class MPILagrangianFieldCommunicator3D:
             raise RuntimeError("Lagrangian node is found outside of Eulerian domain!")
         return cz.astype(np.int32)
 
-    def map_lagrangian_nodes_based_on_position(self, global_lag_positions):
+    def owner_ranks_of(self, global_lag_positions):
+        """Owner rank of every node for these positions (:1386-1394: computed on the master rank, broadcast as M
+        int32), WITHOUT adopting it: the caller compares it with ``rank_address`` to see whether any node has
+        changed slabs before it moves node data around."""
         world = self.mpi_construct.world
         if self.rank == self.master_rank:
             if global_lag_positions.shape[0] != self.grid_dim:
@@ -217,28 +240,53 @@ class MPILagrangianFieldCommunicator3D:
             rank_address = self._compute_lag_nodes_rank_address(global_lag_positions)
         else:
             rank_address = None
-        self.rank_address = world.bcast_object(rank_address, root=self.master_rank)
-        self.local_nodes_idx = np.where(self.rank_address == self.rank)
-        self.local_num_lag_nodes = int(np.count_nonzero(self.rank_address == self.rank))
-        self.slave_ranks_containing_lag_nodes = set(self.rank_address.tolist()) - {self.master_rank}
+        return np.asarray(world.bcast_object(rank_address, root=self.master_rank), dtype=np.int32)
+
+    def adopt_owner_ranks(self, rank_address):
+        self.rank_address = rank_address
+        self.local_nodes_idx = np.where(rank_address == self.rank)
+        self.local_num_lag_nodes = int(np.count_nonzero(rank_address == self.rank))
+        self.slave_ranks_containing_lag_nodes = set(rank_address.tolist()) - {self.master_rank}
+
+    def map_lagrangian_nodes_based_on_position(self, global_lag_positions):
+        self.adopt_owner_ranks(self.owner_ranks_of(global_lag_positions))
+
+    def _owned_by(self, rank):
+        return np.where(self.rank_address == rank)[0]
 
     def scatter_global_field(self, local_lag_field, global_lag_field):
-        """Master's (3, M) host array -> every owner's (3, M_local) host array."""
-        world = self.mpi_construct.world
-        data = world.bcast_object(global_lag_field, root=self.master_rank) if world.size > 1 else global_lag_field
-        idx = np.where(self.rank_address == self.rank)[0]
-        local_lag_field[...] = np.asarray(data)[:, idx]
-
-    def gather_local_field(self, global_lag_field, local_lag_field):
+        """Master's (3, M) host array -> every owner's (3, M_local) host array: the master sends each owner the
+        columns of its nodes, point to point (:1410-1434); ranks without nodes take no part."""
         world = self.mpi_construct.world
         if world.size == 1:
-            global_lag_field[:, np.where(self.rank_address == self.rank)[0]] = local_lag_field
+            local_lag_field[...] = np.asarray(global_lag_field)[:, self._owned_by(self.rank)]
             return
-        parts = [world.bcast_object(np.asarray(local_lag_field) if world.rank == r else None, root=r)
-                 for r in range(world.size)]
         if self.rank == self.master_rank:
-            for r, part in enumerate(parts):
-                global_lag_field[:, np.where(self.rank_address == r)[0]] = part
+            glob = np.asarray(global_lag_field, dtype=local_lag_field.dtype)
+            local_lag_field[...] = glob[:, self._owned_by(self.rank)]
+            world.sendrecv({r: np.ascontiguousarray(glob[:, self._owned_by(r)])
+                            for r in sorted(self.slave_ranks_containing_lag_nodes)}, {})
+        elif self.local_num_lag_nodes:
+            buf = np.empty(local_lag_field.shape, dtype=local_lag_field.dtype)
+            world.sendrecv({}, {self.master_rank: buf})
+            local_lag_field[...] = buf
+
+    def gather_local_field(self, global_lag_field, local_lag_field):
+        """Every owner's (3, M_local) host array -> the master's (3, M), point to point (:1436-1459)."""
+        world = self.mpi_construct.world
+        if world.size == 1:
+            global_lag_field[:, self._owned_by(self.rank)] = local_lag_field
+            return
+        mine = np.ascontiguousarray(local_lag_field)
+        if self.rank == self.master_rank:
+            global_lag_field[:, self._owned_by(self.rank)] = mine
+            parts = {r: np.empty((self.grid_dim, self._owned_by(r).size), dtype=mine.dtype)
+                     for r in sorted(self.slave_ranks_containing_lag_nodes)}
+            world.sendrecv({}, parts)
+            for r, part in parts.items():
+                global_lag_field[:, self._owned_by(r)] = part
+        elif self.local_num_lag_nodes:
+            world.sendrecv({self.master_rank: mine}, {})
 
 
 __all__ = [

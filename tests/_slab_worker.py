@@ -4,6 +4,7 @@ compares with the single-rank oracle on the global grid (the reference's test st
 MPI operator on scattered slabs == serial operator on the gathered array)."""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -63,20 +64,27 @@ if flow_type == "navier_stokes_with_forcing":
     ref = oib.VirtualBoundaryForcing(-2e2 * float(gpu.dx) ** 2, -1e1 * float(gpu.dx) ** 2, 3, cpu.dx, pos.shape[1], g,
                                      eul_real_t=real_t)
 
-for step in range(3):
+interactor_ms = []
+for step in range(4):
     dt = cpu.compute_stable_timestep(dt_prefac=0.5)
     dt_gpu = gpu.compute_stable_timestep(dt_prefac=0.5)
     assert abs(dt_gpu - dt) <= 1e-5 * dt, (dt_gpu, dt)
     if interactor is not None:
+        # the ring drifts along z, 0.7 of a cell per step: nodes change slabs between steps (the mismatch state
+        # must travel with them), while most calls leave the ownership alone
+        pos_now = pos + np.array([0.0, 0.0, 0.7 * step * float(gpu.dx)]).reshape(3, 1)
+        if hasattr(interactor.forcing_grid, "reference_positions"):   # the master rank holds the body
+            interactor.forcing_grid.reference_positions[...] = pos_now
         interactor.time_step(dt)
+        t_host = time.perf_counter()
         interactor()
+        interactor_ms.append(1e3 * (time.perf_counter() - t_host))
         ref.time_step(dt)
-        ref.compute_interaction_force_on_eul_and_lag_grid(cpu.eul_grid_forcing_field, cpu.velocity_field, pos,
+        ref.compute_interaction_force_on_eul_and_lag_grid(cpu.eul_grid_forcing_field, cpu.velocity_field, pos_now,
                                                           np.zeros_like(pos))
         if rank == 0:
-            assert_close(interactor.global_lag_grid_forcing_field, ref.lag_forcing, np.float32, factor=1.0,  # f64 arrays interpolated from the f32 velocity
-                        
-                         what=f"lag forcing step {step}")
+            assert_close(interactor.global_lag_grid_forcing_field, ref.lag_forcing, np.float32, factor=1.0,
+                         what=f"lag forcing step {step}")  # f64 arrays interpolated from the f32 velocity
     gpu.time_step(dt=dt, free_stream_velocity=fs)
     cpu.time_step(dt=dt, free_stream_velocity=fs)
     got_w = np.zeros((3,) + n, dtype=real_t) if rank == 0 else None
@@ -86,6 +94,15 @@ for step in range(3):
     if rank == 0:
         assert_close(got_w, cpu.vorticity_field[inner], real_t, factor=1.0 + 0.5 * step, what=f"vorticity step {step}")
         assert_close(got_u, cpu.velocity_field[inner], real_t, factor=1.0 + 0.5 * step, what=f"velocity step {step}")
+if interactor is not None:
+    # the mismatch state followed the nodes from slab to slab: gathered, it equals the single-rank oracle's
+    interactor.time_step(dt)
+    ref.time_step(dt)
+    interactor.sync_global_mismatch_fields()
+    if rank == 0:
+        assert_close(interactor.global_lag_grid_position_mismatch_field, ref.lag_position_mismatch, np.float32,
+                     what="position mismatch after nodes changed slabs")
+        print(f"host ms per interactor() call at {size} ranks: " + " ".join(f"{t:.2f}" for t in interactor_ms))
 mv = gpu.get_max_vorticity()
 assert abs(float(mv) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(float(cpu.get_max_vorticity()))
 world.barrier()

@@ -6,7 +6,11 @@ bench.py reads (HBM traffic per launch, VALU issue utilisation).
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import lib_source_hash  # noqa: E402
 
 SLOTS = {  # profiler slot of the library -> kernel name prefix in the rocprofv3 tables
     "fft_z_conv": "void k_fft_z_conv<",
@@ -66,6 +70,8 @@ def main():
                   "tools/micro/valu_rate.hip).",
         "grid": [grid] * 3,
         "dtype": "f32",
+        # the counters describe THIS build of the kernels: bench.py withholds them when the sources have changed
+        "lib_source_sha256": lib_source_hash(),
         "kernels": kernels,
     }
     with open(out, "w") as f:
