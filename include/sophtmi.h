@@ -170,9 +170,10 @@ int smi_advection_flux_eno3(smi_ctx* ctx, void* flux, void* field, void* velocit
 int smi_reduce_max_abs_sum(smi_ctx* ctx, const void* vector_field, double* out);
 int smi_reduce_max(smi_ctx* ctx, const void* field, int ncomp, double* out);
 /* max over the interior of |u_x| + |u_y| + |u_z| (compute_stable_timestep, flow_simulators_mpi_3d.py:426-449)
- * of the velocity the last smi_flow_step_ns3d on ctx wrote, gathered by that step's curl kernel: no pass over
- * the field.  Returns an error when no such value is at hand; it does not see later writes to the field. */
-int smi_step_velocity_max_abs_sum(smi_ctx* ctx, double* out);
+ * of the velocity array `velocity` as the last smi_flow_step_ns3d on ctx wrote it, gathered by that step's curl
+ * kernel: no pass over the field.  Returns an error when no such value is at hand or when that step wrote another
+ * array; it does not see later writes to the field. */
+int smi_step_velocity_max_abs_sum(smi_ctx* ctx, const void* velocity, double* out);
 int smi_reduce_sum_sq(smi_ctx* ctx, const void* field, int ncomp, double* out);
 
 /* ---- unbounded Poisson solver ---------------------------------------------------

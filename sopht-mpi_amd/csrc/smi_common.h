@@ -46,6 +46,7 @@ struct smi_ctx {
   void* umax_slots;
   int umax_valid;
   double umax_band;
+  const void* umax_field;  // the velocity array that maximum belongs to
 };
 constexpr int kUmaxSlots = 64;
 

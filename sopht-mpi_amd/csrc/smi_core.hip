@@ -446,9 +446,11 @@ extern "C" int smi_reduce_max_abs_sum(smi_ctx* c, const void* vector_field, doub
 // the way: no pass over the field.  Fails when no such value is at hand (no fused step yet, or the step ran
 // its scalar-path curl); the caller then reduces the field.  It does not know whether the velocity field
 // has been written since: that is the caller's book-keeping.
-extern "C" int smi_step_velocity_max_abs_sum(smi_ctx* c, double* out) {
-  SMI_REQUIRE(c && out, "smi_step_velocity_max_abs_sum: null argument");
+extern "C" int smi_step_velocity_max_abs_sum(smi_ctx* c, const void* velocity, double* out) {
+  SMI_REQUIRE(c && velocity && out, "smi_step_velocity_max_abs_sum: null argument");
   SMI_REQUIRE(c->umax_valid, "smi_step_velocity_max_abs_sum: no fused step has recorded the maximum");
+  SMI_REQUIRE(c->umax_field == velocity,
+              "smi_step_velocity_max_abs_sum: the recorded maximum belongs to another velocity array of this context");
   unsigned long long bits[kUmaxSlots];
   const size_t es = smi_elem_size(c);
   SMI_CHECK_HIP(hipMemcpyAsync(bits, c->umax_slots, es * kUmaxSlots, hipMemcpyDeviceToHost, c->stream));

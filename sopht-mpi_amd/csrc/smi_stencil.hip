@@ -1220,8 +1220,8 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
   Geo G = make_geo(c);
   bool added = add == nullptr;
   c->umax_valid = 0;
-  if (track_max)
-    SMI_CHECK_HIP(hipMemsetAsync(c->umax_slots, 0, sizeof(unsigned long long) * kUmaxSlots, c->stream));
+  if (track_max)  // a fill kernel, not hipMemsetAsync: the step may be captured into a graph by a caller
+    SMI_CHECK(smi_memset_zero(c, c->umax_slots, sizeof(unsigned long long) * kUmaxSlots));
   {
     SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
     SMI_DISPATCH(c, {
@@ -1236,6 +1236,7 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
         // cells outside the compute set (the zeroed bands) hold the constant alone
         c->umax_band = (double)(fabs(a.x) + fabs(a.y) + fabs(a.z));
         c->umax_valid = 1;
+        c->umax_field = out;
       }
     } else if (vec_ok<T>(c, out, f)) {
       LaunchShape s = plan<4>(c, 1);

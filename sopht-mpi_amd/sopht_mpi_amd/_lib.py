@@ -73,7 +73,7 @@ SIGNATURES = {
     "smi_rotational_advection_update": [_p, _p, _p, _p, _d],
     "smi_reduce_max_abs_sum": [_p, _p, _dp],
     "smi_reduce_max": [_p, _p, _i, _dp],
-    "smi_step_velocity_max_abs_sum": [_p, _dp],
+    "smi_step_velocity_max_abs_sum": [_p, _p, _dp],
     "smi_reduce_sum_sq": [_p, _p, _i, _dp],
     "smi_poisson_create": [_pp, _p, _i, _i, _i, _d, _d, _i],
     "smi_poisson_destroy": [_p],
