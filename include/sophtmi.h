@@ -231,6 +231,13 @@ int smi_ib_interpolate(smi_ctx* ctx, void* lag_field, const void* eul_field, con
                        const void* nearest_index, int64_t m, int ncomp, double dx);
 int smi_ib_spread(smi_ctx* ctx, void* eul_field, const void* lag_field, const void* weights,
                   const void* nearest_index, int64_t m, int ncomp);
+/* Choice of the scatter-add in smi_ib_spread / smi_ib_spread_fused on this context.  off (default): one wave per
+ * node, one floating-point atomic add per window cell; overlapping windows accumulate in whatever order the hardware
+ * serves them, so the last bits differ from run to run.  on: the nodes are added one after the other in index order,
+ * each with a single rounding to the field type, as the reference's serial loop over nodes does
+ * (EulerianLagrangianGridCommunicatorMPI3D.py:404-425): reproducible and in the reference's order, a few microseconds
+ * per node; meant for parity runs. */
+int smi_set_ordered_spread(smi_ctx* ctx, int on);
 /* MPIGhostSumCommunicator3D.ghost_sum (EulerianLagrangianGridCommunicatorMPI3D.py:677-792) */
 int smi_ghost_sum(smi_ctx* ctx, void* field, int ncomp);
 /* MPIGhostSumCommunicator3D.clear_ghost_cells (:786-792) */

@@ -47,6 +47,7 @@ struct smi_ctx {
   int umax_valid;
   double umax_band;
   const void* umax_field;  // the velocity array that maximum belongs to
+  int ordered_spread;      // smi_set_ordered_spread: Lagrangian -> Eulerian spreading adds nodes in index order
 };
 constexpr int kUmaxSlots = 64;
 

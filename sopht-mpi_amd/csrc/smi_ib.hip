@@ -249,6 +249,41 @@ __global__ void __launch_bounds__(256) k_ib_spread_fused(T* __restrict__ eul, co
   for (int c = 0; c < 3; ++c) atomicAdd(eul + c * G.vol + off, (T)(forcing[c * m + node] * w));
 }
 
+// Node-ordered spreading (smi_set_ordered_spread): one wave per component walks the nodes in index order and adds
+// each node's 4^3 window with a load, an add in double and a store, like the reference's serial loop over nodes
+// (EulerianLagrangianGridCommunicatorMPI3D.py:404-425: field[window] += force * weights, one node after the other),
+// so overlapping windows accumulate in node order with one rounding to the field type per node and the result does
+// not depend on how the hardware schedules atomics.  The loads and stores are device-scope atomic accesses (they
+// bypass the per-CU cache); the wave issues them in program order, and accesses to one address reach the same L2
+// channel in that order.  A few microseconds per node: for parity runs, not for production.
+// WEIGHTS: materialised weights / index arrays (smi_ib_spread) instead of positions (smi_ib_spread_fused).
+template <typename T, bool WEIGHTS>
+__global__ void __launch_bounds__(64) k_ib_spread_ordered(T* __restrict__ eul, const double* __restrict__ forcing,
+                                                          const double* __restrict__ pos,
+                                                          const double* __restrict__ weights,
+                                                          const long long* __restrict__ index, long long m, IbGeo G,
+                                                          int kernel_type, DeltaConst dc) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  T* field = eul + (long long)c * G.vol;
+  for (long long node = 0; node < m; ++node) {
+    long long ix, iy, iz;
+    double w;
+    if (WEIGHTS) {
+      ix = index[node], iy = index[m + node], iz = index[2 * m + node];
+      w = weights[(long long)lane * m + node];
+    } else {
+      const double X = pos[node], Y = pos[m + node], Z = pos[2 * m + node];
+      ix = nearest_idx(X, G, G.lsx), iy = nearest_idx(Y, G, G.lsy), iz = nearest_idx(Z, G, G.lsz);
+      w = lane_weight(G, X, Y, Z, ix, iy, iz, lane, kernel_type, dc);
+    }
+    long long off;
+    if (!window_cell(G, ix, iy, iz, lane, off)) continue;
+    const double add = forcing[c * m + node] * w;
+    const T old = __hip_atomic_load(field + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(field + off, (T)((double)old + add), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_axpy_f64(double* __restrict__ y, const double* __restrict__ x, long long n,
                                                   double a) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,6 +342,15 @@ extern "C" int smi_ib_spread(smi_ctx* c, void* eul_field, const void* lag_field,
   if (m == 0) return 0;
   int64_t zero3[3] = {0, 0, 0};
   IbGeo G = make_ibgeo(c, 1.0, 0.0, zero3);
+  if (c->ordered_spread) {
+    SMI_DISPATCH(c, {
+      k_ib_spread_ordered<T, true><<<ncomp, 64, 0, c->stream>>>((T*)eul_field, (const double*)lag_field, nullptr,
+                                                               (const double*)weights,
+                                                               (const long long*)nearest_index, m, G, 0, DeltaConst{});
+    });
+    SMI_LAUNCH_CHECK();
+    return 0;
+  }
   SMI_DISPATCH(c, {
     k_ib_spread<T><<<node_blocks(m), 256, 0, c->stream>>>((T*)eul_field, (const double*)lag_field,
                                                          (const double*)weights, (const long long*)nearest_index, m,
@@ -354,11 +398,26 @@ extern "C" int smi_ib_spread_fused(smi_ctx* c, void* eul_forcing, const void* la
   DeltaConst dc = make_delta_const(c, dx);
   // per node: 64 window cells x 3 components read-modify-written
   SmiProfScope prof(c, PROF_IB_SPREAD, (double)m * (64.0 * 3 * 2 * smi_elem_size(c) + 48.0));
+  if (c->ordered_spread) {
+    SMI_DISPATCH(c, {
+      k_ib_spread_ordered<T, false><<<3, 64, 0, c->stream>>>((T*)eul_forcing, (const double*)lag_forcing,
+                                                            (const double*)lag_positions, nullptr, nullptr, m, G,
+                                                            kernel_type, dc);
+    });
+    SMI_LAUNCH_CHECK();
+    return 0;
+  }
   SMI_DISPATCH(c, {
     k_ib_spread_fused<T><<<node_blocks(m), 256, 0, c->stream>>>((T*)eul_forcing, (const double*)lag_forcing,
                                                                (const double*)lag_positions, m, G, kernel_type, dc);
   });
   SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi_set_ordered_spread(smi_ctx* c, int on) {
+  SMI_REQUIRE(c, "smi_set_ordered_spread: null context");
+  c->ordered_spread = on != 0;
   return 0;
 }
 

@@ -51,6 +51,15 @@ class DeviceContext:
         self.padded_shape = tuple(n + 2 * self.ghost_size for n in self.local_grid_size)
         self.transport = "none" if nranks == 1 else None
         self._cb = None
+        if os.environ.get("SOPHT_MI_ORDERED_SPREAD", "0") not in ("", "0"):
+            self.set_ordered_spread(True)
+
+    def set_ordered_spread(self, on=True):
+        """Lagrangian -> Eulerian spreading on this context adds the nodes one after the other in index order (the
+        reference's serial loop: reproducible, in the reference's order, slow) instead of with floating-point
+        atomics.  For parity runs; also switched on by SOPHT_MI_ORDERED_SPREAD=1."""
+        call("smi_set_ordered_spread", self.handle, 1 if on else 0)
+        self.ordered_spread = bool(on)
 
     # -- transports ---------------------------------------------------------------
     def init_rccl(self):
