@@ -41,7 +41,7 @@ def _run_cycles(gpu, cpu, interactor, ref, forcing_grid, cycles, substeps, free_
             interactor.compute_flow_forces_and_torques()
             ref.compute_interaction_force_on_lag_grid(cpu.velocity_field, forcing_grid.position_field,
                                                       forcing_grid.velocity_field)
-            assert_close(interactor.global_lag_grid_forcing_field, ref.lag_forcing, np.float32,
+            assert_close(interactor.global_lag_grid_forcing_field, ref.lag_forcing, np.float32, factor=2.0 + 2.0 * cycle,
                          what=f"node forces, cycle {cycle}")
             assert np.all(np.isfinite(interactor.body_flow_forces)) and np.all(np.isfinite(interactor.body_flow_torques))
         # ... then the mismatch state advances, the forces are spread, and the flow steps
@@ -50,7 +50,10 @@ def _run_cycles(gpu, cpu, interactor, ref, forcing_grid, cycles, substeps, free_
         interactor()
         ref.compute_interaction_force_on_eul_and_lag_grid(cpu.eul_grid_forcing_field, cpu.velocity_field,
                                                           forcing_grid.position_field, forcing_grid.velocity_field)
-        assert_close(gpu.eul_grid_forcing_field.get(), cpu.eul_grid_forcing_field, real_t, what=f"Eulerian forcing {cycle}")
+        # the forces amplify the round-off of the interpolated velocity by the (large) penalty coefficients:
+        # measured 2.4e-6 of the largest forcing in the second cycle of the rod case
+        assert_close(gpu.eul_grid_forcing_field.get(), cpu.eul_grid_forcing_field, real_t, factor=4.0 + 2.0 * cycle,
+                     what=f"Eulerian forcing {cycle}")
         gpu.time_step(dt=dt, free_stream_velocity=free_stream)
         cpu.time_step(dt=dt, free_stream_velocity=free_stream)
         assert_close(gpu.vorticity_field.get()[inner], cpu.vorticity_field[inner], real_t, factor=1.0 + cycle,
@@ -58,7 +61,7 @@ def _run_cycles(gpu, cpu, interactor, ref, forcing_grid, cycles, substeps, free_
         assert_close(gpu.velocity_field.get()[inner], cpu.velocity_field[inner], real_t, factor=2.0 + cycle,
                      what=f"velocity, cycle {cycle}")
     assert_close(interactor.local_lag_grid_position_mismatch_field.get(), ref.lag_position_mismatch, np.float32,
-                 what="position mismatch")
+                 factor=4.0, what="position mismatch")
 
 
 def _interactor_pair(gpu, cpu, cls, body_kw, body, grid_cls, stiffness, damping, **grid_kw):
