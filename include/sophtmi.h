@@ -144,6 +144,14 @@ int smi_update_vorticity_from_velocity_forcing(smi_ctx* ctx, void* vorticity, vo
  * out = vorticity + prefactor * curl(velocity x vorticity) on the cells the update writes,
  * out = vorticity elsewhere.  `out` must not alias the inputs; all three are vector fields. */
 int smi_rotational_advection_update(smi_ctx* ctx, void* out, void* velocity, void* vorticity, double prefactor);
+/* The advection and the diffusion of rotational_form_navier_stokes_timestep (flow_simulators_mpi_3d.py:395-411:
+ * cross product, vorticity update with dt / (2 dx), vector diffusion timestep with nu dt / dx^2), written to another
+ * array: out = w* + c lap7(w*) where the diffusion flux is not zeroed, w* elsewhere, w* = the result of
+ * smi_rotational_advection_update.  One pass over the arrays where the context allows it (single rank, single
+ * precision, 16-byte aligned rows), otherwise the two operators through `scratch` (a vector field).  No array may
+ * alias another. */
+int smi_advection_diffusion_update(smi_ctx* ctx, void* out, void* velocity, void* vorticity, void* scratch,
+                                   double prefactor, double nu_dt_by_dx2);
 /* gen_curl_pyst_mpi_kernel_3d, curl_mpi_3d.py:10-196 */
 int smi_curl(smi_ctx* ctx, void* curl, void* field, double prefactor);
 /* gen_divergence_pyst_mpi_kernel_3d, divergence_mpi_3d.py:10-200 */
@@ -267,6 +275,16 @@ int smi_flow_step_ns3d(smi_ctx* ctx, smi_poisson* p, void* vorticity, void* velo
                        double dt, double nu, double dx, int penalty_width, const double* fac_lo,
                        const double* fac_hi, const double* free_stream, int filter_order,
                        int filter_type);
+/* The same step for a caller that can exchange the roles of `vorticity` and `buffer_vector` afterwards (the two
+ * arrays of flow_simulators_mpi_3d.py:191-194; the reference treats buffer_vector as scratch).  Advection and
+ * diffusion (:395-411) then run as ONE pass from `vorticity` into `buffer_vector` and the rest of the step works on
+ * `buffer_vector`.  *result_in_buffer = 1: the new vorticity is in `buffer_vector`, `vorticity` holds scratch;
+ * 0: the result is in `vorticity`, as with smi_flow_step_ns3d (several ranks, double precision, filter settings
+ * that need the buffer). */
+int smi_flow_step_ns3d_swap(smi_ctx* ctx, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
+                            void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu, double dx,
+                            int penalty_width, const double* fac_lo, const double* fac_hi, const double* free_stream,
+                            int filter_order, int filter_type, int* result_in_buffer);
 /* Optional promise for the next smi_flow_step_ns3d call on ctx (single rank): the forcing field is zero
  * outside the padded-index box [lo, hi] (z, y, x order, inclusive; lo > hi on an axis = zero everywhere;
  * NULL, NULL withdraws it).  The step then runs update_vorticity_from_velocity_forcing

@@ -125,6 +125,8 @@ int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* fiel
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
+int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double pref_curl, double pref_diff,
+                            int* ran);
 int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add,
                              bool track_max = false);
 // forcing update and forcing reset restricted to the rows and planes the support box can reach

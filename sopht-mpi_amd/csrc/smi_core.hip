@@ -485,7 +485,7 @@ static const char* kSlotNames[PROF_NUM_SLOTS] = {
     "cross_product", "curl_update", "diffusion_flux", "elementwise_sum", "laplacian_filter", "penalise",
     "curl", "add_set_fixed", "poisson_pad", "poisson_rocfft_fwd", "poisson_multiply", "poisson_rocfft_inv",
     "poisson_extract", "fft_x_fwd", "fft_y_fwd", "fft_z_conv", "fft_y_inv", "fft_x_inv", "transpose", "halo",
-    "ib_forcing", "ib_spread", "fused_advect", "fused_diffuse", "advection_flux", "flow_step"};
+    "ib_forcing", "ib_spread", "fused_advect", "fused_diffuse", "advection_flux", "fused_advect_diffuse", "flow_step"};
 
 const char* smi_prof_slot_name(int slot) { return slot >= 0 && slot < PROF_NUM_SLOTS ? kSlotNames[slot] : "?"; }
 

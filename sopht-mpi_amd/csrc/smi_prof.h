@@ -32,6 +32,7 @@ enum SmiProfSlot {
   PROF_FUSED_ADVECT,
   PROF_FUSED_DIFFUSE,
   PROF_ADVECTION,
+  PROF_FUSED_ADVECT_DIFFUSE,
   PROF_STEP,  // one whole smi_flow_step_ns3d (brackets the kernel slots above)
   PROF_NUM_SLOTS
 };

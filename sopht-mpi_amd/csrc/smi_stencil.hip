@@ -14,6 +14,8 @@
 //   D = { z in [zlo_c, zhi_c], y and x in [g+1, p-g-2] }   for flux / curl / filter
 //   U = A + B + C                                          for the vorticity update
 // with the sets spelled out at each kernel.
+#include <cstdlib>
+
 #include "smi_common.h"
 #include "smi_prof.h"
 
@@ -614,6 +616,176 @@ __global__ void __launch_bounds__(kTileThreads) k_advect_tiled(T* __restrict__ o
     if (z < ze) halo(z + 1, buf ^ 1);
   }
   for (int z = ze + 1; z < z1; ++z) copy_plane(z);
+}
+
+// ---------------------------------------------------------------- advection + diffusion in one pass
+// out = w* + c lap7(w*) on D, w* elsewhere, with w* = w + p curl(u x w) on U, w elsewhere: the rotational
+// advection update followed by the diffusion timestep (flow_simulators_mpi_3d.py:395-411) without the round trip
+// of the advected vorticity w* through HBM (6 S of 15).  Both stencils have support 1, so an output cell needs w*
+// on its six neighbours and those need b = u x w one cell further out.  A workgroup owns a tile of OY rows x 4 OX
+// columns and runs one lane per 16-byte vector of the region two rows / one vector larger on every side
+// (RY = OY + 4 rows of RX = OX + 2 vectors): every lane loads u and w of its vector and forms b and w*, the lanes of
+// the tile proper also form and store the output.  The region marches along z.  In-plane neighbours of b and of w*
+// come from two sets of LDS tiles, the z - 1 / z + 1 values stay in the lane's registers.  Per plane: park b of
+// plane z + 1 and w* of plane z; barrier; w* of plane z + 1 from b; output of plane z from w*; barrier.
+// The arithmetic (operand order included) is that of k_advect_tiled and k_diffuse_tiled.  Lanes outside the array
+// or in the outer ring read valid memory and compute values nobody uses; selects, not arithmetic, apply the masks.
+struct FusedShape {
+  int rx, ry;      // region: vectors per row, rows
+  int ox, oy;      // tile proper: rx - 2, ry - 4
+  int ntx, nty;    // tiles per plane
+  int pitch;       // LDS row pitch in elements (the lane's vector starts at column 4 + 4 * its index)
+};
+constexpr int kFusedThreads = 1024;
+
+template <typename T>
+__global__ void __launch_bounds__(kFusedThreads) k_advect_diffuse(T* __restrict__ out, const T* __restrict__ vel,
+                                                                 const T* __restrict__ vort, T pref, T cdiff, Geo G,
+                                                                 int zchunk, FusedShape S) {
+  extern __shared__ char smi_tile_smem[];
+  T* lds = reinterpret_cast<T*>(smi_tile_smem);
+  const Blk B = xcd_block<true>();
+  const int tyi = B.x / S.ntx, txi = B.x - tyi * S.ntx;
+  const int tid = threadIdx.x;
+  const int ry = tid / S.rx, rxl = tid - ry * S.rx;
+  const bool lane_on = ry < S.ry;
+  const int y = tyi * S.oy - 2 + ry, x0 = (txi * S.ox - 1 + rxl) * 4;
+  const bool in_arr = lane_on && y >= 0 && y < G.py && x0 >= 0 && x0 < G.px;
+  const bool own = in_arr && ry >= 2 && ry < S.ry - 2 && rxl >= 1 && rxl < S.rx - 1;
+  const long long q = in_arr ? (long long)y * G.px + x0 : 0;
+  const size_t comp = (size_t)(S.ry + 2) * S.pitch;
+  T* tb = lds;              // b_x, b_y, b_z of the plane ahead
+  T* tw = lds + 3 * comp;   // w*_x, w*_y, w*_z of the current plane
+  const int off = (ry + 1) * S.pitch + 4 + 4 * rxl;
+  unsigned mA = 0, mB = 0;  // per cell of the vector: in the sets A (z-dependent) and B of the update set
+  if (in_arr) {
+    const bool yc = in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
+      mA |= (unsigned)(yc && xc) << e;
+      mB |= (unsigned)((yf && xc) || (ye && xf)) << e;
+    }
+  }
+  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  auto plane_of = [&](int z) { return (long long)min(max(z, 0), G.pz - 1) * G.plane + q; };
+  Vec3<T, 4> lu, lw;  // u and w of the plane two ahead, in flight
+  Pack<T, 4> bPx, bPy, bCx, bCy, bCz, dummy;
+  Vec3<T, 4> wC, Zm, Wk;
+  Zm = Wk = Vec3<T, 4>{zero_pack<T, 4>(), zero_pack<T, 4>(), zero_pack<T, 4>()};
+  {
+    lu = ld3<T, 4>(vel + plane_of(z0 - 2), G.vol);
+    lw = ld3<T, 4>(vort + plane_of(z0 - 2), G.vol);
+    cross3(lu.x, lu.y, lu.z, lw.x, lw.y, lw.z, bPx, bPy, dummy);
+    lu = ld3<T, 4>(vel + plane_of(z0 - 1), G.vol);
+    wC = ld3<T, 4>(vort + plane_of(z0 - 1), G.vol);
+    cross3(lu.x, lu.y, lu.z, wC.x, wC.y, wC.z, bCx, bCy, bCz);
+    lu = ld3<T, 4>(vel + plane_of(z0), G.vol);
+    lw = ld3<T, 4>(vort + plane_of(z0), G.vol);
+  }
+  for (int k = z0 - 2; k < z1; ++k) {
+    if (lane_on) {
+      st<T, 4>(tb + off, bCx);
+      st<T, 4>(tb + comp + off, bCy);
+      st<T, 4>(tb + 2 * comp + off, bCz);
+      st<T, 4>(tw + off, Wk.x);
+      st<T, 4>(tw + comp + off, Wk.y);
+      st<T, 4>(tw + 2 * comp + off, Wk.z);
+    }
+    __syncthreads();
+    // b and w of plane k + 2 from the loads issued half a step ago (the request for plane k + 3 follows once the
+    // registers of the curl below are free again: with both in flight the allocation spills)
+    Pack<T, 4> bNx, bNy, bNz;
+    cross3(lu.x, lu.y, lu.z, lw.x, lw.y, lw.z, bNx, bNy, bNz);
+    const Vec3<T, 4> wN = lw;
+    Vec3<T, 4> Wn = wC;
+    if (lane_on) {
+      // w* of plane k + 1
+      const int j = k + 1;
+      const unsigned m = ((j >= 1 && j <= G.pz - 2) ? mB : 0u) | ((j >= G.g && j <= G.pz - G.g - 1) ? mA : 0u);
+      const T* tx = tb + off;
+      const T* ty = tb + comp + off;
+      const T* tz = tb + 2 * comp + off;
+      const Pack<T, 4> bx_ym = ld<T, 4>(tx - S.pitch), bx_yp = ld<T, 4>(tx + S.pitch);
+      const Pack<T, 4> bz_ym = ld<T, 4>(tz - S.pitch), bz_yp = ld<T, 4>(tz + S.pitch);
+      const T by_xm = ty[-1], by_xp = ty[4], bz_xm = tz[-1], bz_xp = tz[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const T byL = e == 0 ? by_xm : bCy.v[e - 1], byR = e == 3 ? by_xp : bCy.v[e + 1];
+        const T bzL = e == 0 ? bz_xm : bCz.v[e - 1], bzR = e == 3 ? bz_xp : bCz.v[e + 1];
+        const T cx = pref * (bz_yp.v[e] - bz_ym.v[e] - bNy.v[e] + bPy.v[e]);
+        const T cy = pref * (bNx.v[e] - bPx.v[e] - bzR + bzL);
+        const T cz = pref * (byR - byL - bx_yp.v[e] + bx_ym.v[e]);
+        const bool on = (m >> e) & 1u;
+        Wn.x.v[e] = on ? wC.x.v[e] + cx : wC.x.v[e];
+        Wn.y.v[e] = on ? wC.y.v[e] + cy : wC.y.v[e];
+        Wn.z.v[e] = on ? wC.z.v[e] + cz : wC.z.v[e];
+      }
+    }
+    if (k + 3 <= z1 + 1) {  // uniform
+      lu = ld3<T, 4>(vel + plane_of(k + 3), G.vol);
+      lw = ld3<T, 4>(vort + plane_of(k + 3), G.vol);
+    }
+    {
+      // output of plane k
+      if (own && k >= z0) {
+        const unsigned d = (k >= G.zlo_c && k <= G.zhi_c) ? mA : 0u;
+        const long long zo = (long long)k * G.plane + q;
+        const Pack<T, 4>* cur3[3] = {&Wk.x, &Wk.y, &Wk.z};
+        const Pack<T, 4>* prv3[3] = {&Zm.x, &Zm.y, &Zm.z};
+        const Pack<T, 4>* nxt3[3] = {&Wn.x, &Wn.y, &Wn.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const T* tc = tw + c * comp + off;
+          const Pack<T, 4> ym = ld<T, 4>(tc - S.pitch), yp = ld<T, 4>(tc + S.pitch);
+          const T xm = tc[-1], xp = tc[4];
+          const Pack<T, 4>& cur = *cur3[c];
+          Pack<T, 4> o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const T left = e == 0 ? xm : cur.v[e - 1], right = e == 3 ? xp : cur.v[e + 1];
+            const T val = cdiff * (right + left + yp.v[e] + ym.v[e] + nxt3[c]->v[e] + prv3[c]->v[e] - T(6) * cur.v[e]);
+            o.v[e] = cur.v[e] + (((d >> e) & 1u) ? val : T(0));
+          }
+          st<T, 4>(out + c * G.vol + zo, o);
+        }
+      }
+    }
+    __syncthreads();
+    bPx = bCx;
+    bPy = bCy;
+    bCx = bNx;
+    bCy = bNy;
+    bCz = bNz;
+    wC = wN;
+    Zm = Wk;
+    Wk = Wn;
+  }
+}
+
+// Region shape for a padded plane of py rows x px / 4 vectors: the (rx, ry) with rx * ry <= kFusedThreads whose tiles
+// (rx - 2 vectors x ry - 4 rows) cover the plane with the fewest lanes, the LDS budget permitting.
+template <typename T>
+static bool fused_shape(const smi_ctx* c, FusedShape& best) {
+  const int nl = c->px / 4;
+  double best_cost = 1e300;
+  bool found = false;
+  for (int rx = 6; rx <= 128; ++rx) {
+    const int ry = kFusedThreads / rx;
+    if (ry < 6) break;
+    const int ox = rx - 2, oy = ry - 4;
+    const int ntx = (nl + ox - 1) / ox, nty = (c->py + oy - 1) / oy;
+    const int pitch = 4 * rx + 8;
+    const size_t lds = (size_t)6 * (ry + 2) * pitch * sizeof(T);
+    if (lds > 150 * 1024) continue;
+    const double cost = (double)ntx * nty * rx * ry;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = FusedShape{rx, ry, ox, oy, ntx, nty, pitch};
+      found = true;
+    }
+  }
+  return found;
 }
 
 // Position of a lane in the branch-free tiled kernels: its own four cells and its share of the
@@ -1355,6 +1527,67 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
   });
   SMI_LAUNCH_CHECK();
   return 0;
+}
+
+// Planes per workgroup of the fused kernel: one workgroup is resident per CU (its LDS tiles take two thirds of the
+// CU's 160 KB), so the launch should fill whole rounds of the chip, and every chunk re-reads four halo planes.
+static int fused_zchunk(const smi_ctx* c, int tiles_per_plane) {
+  static int cus[64] = {};
+  int& n_cu = cus[c->device & 63];
+  if (n_cu == 0 && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
+  if (const char* e = getenv("SMI_FUSED_ZCHUNK")) return atoi(e) > 0 ? atoi(e) : 32;
+  int best = c->pz;
+  double best_eff = 0.0;
+  for (int n = 1; n * 8 <= c->pz; ++n) {
+    const int zc = (c->pz + n - 1) / n;
+    const long long wgs = (long long)tiles_per_plane * ((c->pz + zc - 1) / zc);
+    const long long rounds = (wgs + n_cu - 1) / n_cu;
+    const double eff = (double)wgs / (double)(rounds * n_cu) * zc / (zc + 4.0);
+    if (eff > best_eff) {
+      best_eff = eff;
+      best = zc;
+    }
+  }
+  return best;
+}
+
+// out = advection update followed by the diffusion timestep of `vorticity`, in one pass (k_advect_diffuse).
+// *ran = 0 and nothing is launched when this context is not served by the fused kernel (several ranks: the
+// advected vorticity of the neighbour's edge planes would be needed; double precision: the LDS tiles do not fit;
+// unaligned arrays): the caller then runs the two operators one after the other.
+int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double pref_curl, double pref_diff,
+                            int* ran) {
+  *ran = 0;
+  SMI_REQUIRE(out != velocity && out != vorticity, "advection-diffusion: output and input must not alias");
+  if (smi_multi_rank(c) || c->dtype != SMI_F32 || getenv("SMI_NO_FUSED_ADVECT_DIFFUSE")) return 0;
+  if (!(vec_ok<float>(c, out, velocity) && vec_ok<float>(c, out, vorticity))) return 0;
+  FusedShape S;
+  if (!fused_shape<float>(c, S)) return 0;
+  Geo G = make_geo(c);
+  const size_t lds_bytes = (size_t)6 * (S.ry + 2) * S.pitch * sizeof(float);
+  SMI_CHECK_HIP(hipFuncSetAttribute((const void*)k_advect_diffuse<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));
+  const int zchunk = fused_zchunk(c, S.ntx * S.nty);
+  dim3 grid(S.ntx * S.nty, (c->pz + zchunk - 1) / zchunk, 1);
+  SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
+  k_advect_diffuse<float><<<grid, kFusedThreads, lds_bytes, c->stream>>>((float*)out, (const float*)velocity,
+                                                                        (const float*)vorticity, (float)pref_curl,
+                                                                        (float)pref_diff, G, zchunk, S);
+  SMI_LAUNCH_CHECK();
+  *ran = 1;
+  return 0;
+}
+
+extern "C" int smi_advection_diffusion_update(smi_ctx* c, void* out, void* velocity, void* vorticity, void* scratch,
+                                              double prefactor, double nu_dt_by_dx2) {
+  SMI_REQUIRE(c && out && velocity && vorticity && scratch, "smi_advection_diffusion_update: bad argument");
+  SMI_REQUIRE(scratch != out && scratch != velocity && scratch != vorticity,
+              "smi_advection_diffusion_update: the scratch array must not alias the others");
+  int ran = 0;
+  SMI_CHECK(smi_advect_diffuse_impl(c, out, velocity, vorticity, prefactor, nu_dt_by_dx2, &ran));
+  if (ran) return 0;
+  SMI_CHECK(smi_advect_vorticity_impl(c, scratch, velocity, vorticity, prefactor));
+  return smi_diffusion_apply_impl(c, out, scratch, nu_dt_by_dx2, 3);
 }
 
 extern "C" int smi_rotational_advection_update(smi_ctx* c, void* out, void* velocity, void* vorticity,

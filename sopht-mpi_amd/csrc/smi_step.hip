@@ -6,26 +6,50 @@
 static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
                           void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu, double dx,
                           int penalty_width, const double* fac_lo, const double* fac_hi, const double* free_stream,
-                          int filter_order, int filter_type);
+                          int filter_order, int filter_type, int* result_in_buffer);
 
 // Every stencil of this step reads one ghost plane (kernel support 1) and every operator
 // refreshes the ghost planes of its own input, so only the plane next to the interior needs to
 // travel: half the halo bytes of the reference's full-depth exchange.  (The second ghost plane
 // then holds stale values; nothing inside the step reads them into interior cells.)
-extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
-                                  void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
-                                  double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
-                                  const double* free_stream, int filter_order, int filter_type) {
+static int flow_step(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
+                     void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu, double dx,
+                     int penalty_width, const double* fac_lo, const double* fac_hi, const double* free_stream,
+                     int filter_order, int filter_type, int* result_in_buffer) {
   SMI_REQUIRE(c, "smi_flow_step_ns3d: null context");
   const int saved = c->halo_depth;
   const bool shallow = filter_order == 0 || (filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE);
   if (shallow) c->halo_depth = 1;
   SmiProfScope prof(c, PROF_STEP, 0.0);
   const int rc = flow_step_body(c, p, vorticity, velocity, stream_func, buffer_vector, buffer_scalar, forcing, dt, nu,
-                                dx, penalty_width, fac_lo, fac_hi, free_stream, filter_order, filter_type);
+                                dx, penalty_width, fac_lo, fac_hi, free_stream, filter_order, filter_type,
+                                result_in_buffer);
   c->halo_depth = saved;
   c->fbox_valid = 0;  // the promise covered this step only
   return rc;
+}
+
+extern "C" int smi_flow_step_ns3d(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
+                                  void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
+                                  double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
+                                  const double* free_stream, int filter_order, int filter_type) {
+  return flow_step(c, p, vorticity, velocity, stream_func, buffer_vector, buffer_scalar, forcing, dt, nu, dx,
+                   penalty_width, fac_lo, fac_hi, free_stream, filter_order, filter_type, nullptr);
+}
+
+// The same step for a caller that can exchange the roles of `vorticity` and `buffer_vector` afterwards: advection and
+// diffusion then run as ONE pass from `vorticity` into `buffer_vector`, and the rest of the step (penalisation,
+// Poisson solves) works on `buffer_vector`.  *result_in_buffer = 1 says that this happened: the new vorticity is in
+// `buffer_vector` and `vorticity` holds scratch; 0: the result is in `vorticity` as with smi_flow_step_ns3d.
+extern "C" int smi_flow_step_ns3d_swap(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
+                                       void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
+                                       double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
+                                       const double* free_stream, int filter_order, int filter_type,
+                                       int* result_in_buffer) {
+  SMI_REQUIRE(result_in_buffer, "smi_flow_step_ns3d_swap: null result_in_buffer");
+  *result_in_buffer = 0;
+  return flow_step(c, p, vorticity, velocity, stream_func, buffer_vector, buffer_scalar, forcing, dt, nu, dx,
+                   penalty_width, fac_lo, fac_hi, free_stream, filter_order, filter_type, result_in_buffer);
 }
 
 // Promise for the NEXT smi_flow_step_ns3d on this context: its forcing field is exactly zero outside the
@@ -50,7 +74,8 @@ extern "C" int smi_set_forcing_support(smi_ctx* c, const int* lo_zyx, const int*
 static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
                                   void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
                                   double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
-                                  const double* free_stream, int filter_order, int filter_type) {
+                                  const double* free_stream, int filter_order, int filter_type,
+                                  int* result_in_buffer) {
   SMI_REQUIRE(c && p && vorticity && velocity && stream_func && buffer_vector && buffer_scalar,
               "smi_flow_step_ns3d: null argument");
   // the prefactors are rounded to the real type exactly as the reference does with real_t(...)
@@ -69,25 +94,41 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
     SMI_CHECK(smi_forcing_update_boxed_impl(c, vorticity, forcing, pref_curl));
   else if (forcing)
     SMI_CHECK(smi_update_vorticity_from_velocity_forcing(c, vorticity, forcing, pref_curl));
-  // Advection and diffusion ping-pong between arrays so each runs as a single pass: the
-  // advected vorticity w + dt/(2dx) curl(u x w) lands in buffer_vector (u x w itself only ever
-  // exists in registers) and the diffusion step brings it back into vorticity.
-  SMI_CHECK(smi_advect_vorticity_impl(c, buffer_vector, velocity, vorticity, pref_curl));
-  if (filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE) {
-    // the common filter setting runs as one more single pass: diffuse into the (still dead) stream
-    // function array, filter from there back into vorticity
-    SMI_CHECK(smi_diffusion_apply_impl(c, stream_func, buffer_vector, pref_diff, 3));
-    SMI_CHECK(smi_filter_apply_impl(c, vorticity, stream_func, 3));
+  // Advection and diffusion ping-pong between arrays so that each runs as a single pass: the advected vorticity
+  // w + dt/(2dx) curl(u x w) lands in buffer_vector (u x w itself only ever exists in registers) and the diffusion
+  // step brings it back into vorticity.  Where the fused kernel serves this context both run as ONE pass into
+  // buffer_vector; the result then either comes back through the filter pass, or stays there when the caller has
+  // said that it can exchange the two arrays.
+  const bool filter1 = filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE;
+  void* w_new = vorticity;  // where the advected, diffused, filtered vorticity ends up
+  int fused = 0;
+  if (filter1 || (filter_order == 0 && result_in_buffer))
+    SMI_CHECK(smi_advect_diffuse_impl(c, buffer_vector, velocity, vorticity, pref_curl, pref_diff, &fused));
+  if (fused) {
+    if (filter1) {
+      SMI_CHECK(smi_filter_apply_impl(c, vorticity, buffer_vector, 3));
+    } else {
+      w_new = buffer_vector;
+      *result_in_buffer = 1;
+    }
   } else {
-    SMI_CHECK(smi_diffusion_apply_impl(c, vorticity, buffer_vector, pref_diff, 3));
-    if (filter_order > 0) {
-      size_t stride = c->vol * smi_elem_size(c);
-      SMI_CHECK(smi_laplacian_filter(c, vorticity, 3, buffer_vector, (char*)buffer_vector + stride, filter_order,
-                                     filter_type));
+    SMI_CHECK(smi_advect_vorticity_impl(c, buffer_vector, velocity, vorticity, pref_curl));
+    if (filter1) {
+      // the common filter setting runs as one more single pass: diffuse into the (still dead) stream function
+      // array, filter from there back into vorticity
+      SMI_CHECK(smi_diffusion_apply_impl(c, stream_func, buffer_vector, pref_diff, 3));
+      SMI_CHECK(smi_filter_apply_impl(c, vorticity, stream_func, 3));
+    } else {
+      SMI_CHECK(smi_diffusion_apply_impl(c, vorticity, buffer_vector, pref_diff, 3));
+      if (filter_order > 0) {
+        size_t stride = c->vol * smi_elem_size(c);
+        SMI_CHECK(smi_laplacian_filter(c, vorticity, 3, buffer_vector, (char*)buffer_vector + stride, filter_order,
+                                       filter_type));
+      }
     }
   }
-  SMI_CHECK(smi_penalise_boundary(c, vorticity, 3, penalty_width, fac_lo, fac_hi));
-  SMI_CHECK(smi_poisson_vector_solve(p, stream_func, vorticity));
+  SMI_CHECK(smi_penalise_boundary(c, w_new, 3, penalty_width, fac_lo, fac_hi));
+  SMI_CHECK(smi_poisson_vector_solve(p, stream_func, w_new));
   // curl and the free stream in one pass over the velocity array
   SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream, /*track_max=*/true));
   if (boxed) {

@@ -71,6 +71,7 @@ SIGNATURES = {
     "smi_advection_timestep_eno3": [_p, _p, _p, _p, _d, _i],
     "smi_advection_flux_eno3": [_p, _p, _p, _p, _d],
     "smi_rotational_advection_update": [_p, _p, _p, _p, _d],
+    "smi_advection_diffusion_update": [_p, _p, _p, _p, _p, _d, _d],
     "smi_reduce_max_abs_sum": [_p, _p, _dp],
     "smi_reduce_max": [_p, _p, _i, _dp],
     "smi_step_velocity_max_abs_sum": [_p, _p, _dp],
@@ -122,6 +123,8 @@ SIGNATURES = {
     "smi2d_ib_spread": [_p, _p, _p, _p, _p, C.c_int64, _i, _i],
     "smi_set_forcing_support": [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "smi_flow_step_ns3d": [_p, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _i, _dp, _dp, _dp, _i, _i],
+    "smi_flow_step_ns3d_swap": [_p, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _i, _dp, _dp, _dp, _i, _i,
+                                C.POINTER(C.c_int)],
 }
 _SPECIAL = {
     "smi_last_error": (C.c_char_p, []),

@@ -306,6 +306,17 @@ class DeviceField:
         host[idx] = np.asarray(values)
         self.set(host)
 
+    def exchange_storage_with(self, other):
+        """Trade device storage with ``other`` (same shape and type, both whole allocations): afterwards each field,
+        and every view of it, addresses the memory the other one had.  No data moves."""
+        if (other.shape != self.shape or other.dtype != self.dtype or self._offset or other._offset
+                or self._alloc is other._alloc):
+            raise ValueError("fields must be distinct whole allocations of the same shape and type")
+        a, b = self._alloc, other._alloc
+        a.ptr, b.ptr = b.ptr, a.ptr
+        a.support, b.support = b.support, a.support
+        a.derived, b.derived = b.derived, a.derived
+
     def copy(self):
         out = DeviceField(self.ctx, self.shape, self.dtype, zero=False)
         call("smi_memcpy_d2d", self.ctx.handle, out.ptr, self.tracked_ptr(), self.nbytes)

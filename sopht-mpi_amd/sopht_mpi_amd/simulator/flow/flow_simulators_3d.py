@@ -207,17 +207,22 @@ class UnboundedFlowSimulator3D(UnboundedFlowSimulatorBase):
         order, ftype = 0, 0
         if self.filter_setting_dict is not None:
             order, ftype = int(self.filter_setting_dict["order"]), _FILTER_CODES[self.filter_setting_dict["type"]]
+        result_in_buffer = C.c_int(0)
         try:
-            call("smi_flow_step_ns3d", self.ctx.handle, self.unbounded_poisson_solver.handle,
+            call("smi_flow_step_ns3d_swap", self.ctx.handle, self.unbounded_poisson_solver.handle,
                  as_ptr(self.vorticity_field), as_ptr(self.velocity_field), as_ptr(self.stream_func_field),
                  as_ptr(self.buffer_vector_field), as_ptr(self.buffer_scalar_field), forcing, float(dt),
                  float(self.kinematic_viscosity), float(self.dx), int(self.penalty_zone_width), lo, hi, free_stream,
-                 order, ftype)
+                 order, ftype, C.byref(result_in_buffer))
         except Exception:
             # a step that failed part-way says nothing about where the forcing is non-zero
             if forcing_field is not None:
                 forcing_field._alloc.support = None
             raise
+        if result_in_buffer.value:
+            # the step left the new vorticity in the buffer array: the two allocations trade places (every view
+            # of either field shares its allocation object and follows)
+            self.vorticity_field.exchange_storage_with(self.buffer_vector_field)
         if forcing_field is not None:
             forcing_field._alloc.support = EMPTY_SUPPORT   # the step ended with the reset
         # the step's curl kernel has gathered max |u|_1 of the velocity it wrote (compute_stable_timestep)

@@ -261,3 +261,46 @@ def test_tiled_kernels_on_random_shapes(smi, shape, g):
     want = f.copy()
     st.update_vorticity_from_velocity_forcing(want, cross, c, g)
     assert_close(dout.get(), want, real_t, factor=1.0, what="rotational advection update")
+    # ... followed by the diffusion timestep, as one operator (one pass in single precision)
+    dscr = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    dout2 = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    c2 = real_t(0.093)
+    _call(smi, "smi_advection_diffusion_update", ctx.handle, dout2.ptr, du.ptr, df.ptr, dscr.ptr, float(c), float(c2))
+    st.vector_diffusion_timestep(want, np.zeros(ctx.padded_shape, dtype=real_t), c2, g)
+    assert_close(dout2.get(), want, real_t, factor=2.0, what="advection + diffusion update")
+    assert np.array_equal(du.get(), u) and np.array_equal(df.get(), f), "inputs were modified"
+
+
+@pytest.mark.parametrize("zchunk", [None, "8", "13"])
+@pytest.mark.parametrize("shape,g", [((40, 70, 260), 2), ((24, 100, 60), 2), ((8, 8, 8), 2), ((33, 45, 124), 2),
+                                     ((16, 16, 34), 3), ((50, 21, 512), 2)])
+def test_fused_advection_diffusion_shapes(smi, shape, g, zchunk, monkeypatch):
+    """The one-pass advection + diffusion kernel (single precision) on grids with one to several tiles per plane,
+    partial tiles in both directions and, through SMI_FUSED_ZCHUNK, one to several z chunks with partial last
+    chunks: against the reference's operator sequence (cross product, vorticity update, diffusion timestep)
+    on the whole array, ghost cells included, and against the two-pass path of the library bit for bit."""
+    real_t = np.float32
+    if zchunk is not None:
+        monkeypatch.setenv("SMI_FUSED_ZCHUNK", zchunk)
+    rng = np.random.default_rng(sum(shape))
+    ctx = make_ctx(smi, shape, g, real_t)
+    assert ctx.padded_shape[2] % 4 == 0
+    u = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    w = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    p, c = real_t(0.211), real_t(0.093)
+    du, dw = ctx.from_numpy(u), ctx.from_numpy(w)
+    dscr = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    dout = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    _call(smi, "smi_advection_diffusion_update", ctx.handle, dout.ptr, du.ptr, dw.ptr, dscr.ptr, float(p), float(c))
+    cross = np.zeros_like(w)
+    st.elementwise_cross_product(cross, u, w)
+    want = w.copy()
+    st.update_vorticity_from_velocity_forcing(want, cross, p, g)
+    st.vector_diffusion_timestep(want, np.zeros(ctx.padded_shape, dtype=real_t), c, g)
+    assert_close(dout.get(), want, real_t, factor=2.0, what="advection + diffusion, one pass")
+    # the two-pass path of the library: same arithmetic in the same order
+    monkeypatch.setenv("SMI_NO_FUSED_ADVECT_DIFFUSE", "1")
+    dout2 = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    _call(smi, "smi_advection_diffusion_update", ctx.handle, dout2.ptr, du.ptr, dw.ptr, dscr.ptr, float(p), float(c))
+    assert np.array_equal(dout.get(), dout2.get()), "one pass and two passes must agree bit for bit"
+    assert np.array_equal(du.get(), u) and np.array_equal(dw.get(), w), "inputs were modified"
