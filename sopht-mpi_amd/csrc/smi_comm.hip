@@ -51,6 +51,10 @@ static inline ncclDataType_t nccl_type(const smi_ctx* c) { return c->dtype == SM
 // fused step has lowered halo_depth to what its stencils read.  Two fields may travel in one
 // group (one launch): the velocity and the vorticity ahead of the fused advection.
 int smi_halo_exchange2_impl(smi_ctx* c, void* field_a, int ncomp_a, void* field_b, int ncomp_b) {
+  return smi_halo_exchange2_on(c, field_a, ncomp_a, field_b, ncomp_b, c->stream);
+}
+
+int smi_halo_exchange2_on(smi_ctx* c, void* field_a, int ncomp_a, void* field_b, int ncomp_b, hipStream_t stream) {
   if (c->nranks == 1) return 0;
   const int d = (c->halo_depth > 0 && c->halo_depth < c->g) ? c->halo_depth : c->g;
   void* fields[2] = {field_a, field_b};
@@ -71,15 +75,15 @@ int smi_halo_exchange2_impl(smi_ctx* c, void* field_a, int ncomp_a, void* field_
     for (int k = 0; k < ncomps[f]; ++k) {
       char* p = (char*)fields[f] + (size_t)k * c->vol * es;
       if (c->rank > 0) {
-        SMI_CHECK_NCCL(ncclSend(p + (size_t)c->g * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclSend(p + (size_t)c->g * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm, stream));
         SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->g - d) * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm,
-                                c->stream));
+                                stream));
       }
       if (c->rank < c->nranks - 1) {
         SMI_CHECK_NCCL(ncclSend(p + (size_t)(c->pz - c->g - d) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
-                                c->stream));
+                                stream));
         SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
-                                c->stream));
+                                stream));
       }
     }
   SMI_CHECK_NCCL(ncclGroupEnd());

@@ -122,6 +122,8 @@ __device__ __forceinline__ void store4(T* p, const Vec4<T>& v) {
 // internal cross-TU helpers
 int smi_halo_exchange_impl(smi_ctx* ctx, void* field, int ncomp);
 int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* field_b, int ncomp_b);
+// the same exchange queued on `stream` (RCCL transport only: the host-staged callback works on the context's stream)
+int smi_halo_exchange2_on(smi_ctx* ctx, void* field_a, int ncomp_a, void* field_b, int ncomp_b, hipStream_t stream);
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);

@@ -25,6 +25,10 @@ struct Geo {
   int pz, py, px, g;
   long long plane, vol;
   int zlo_c, zhi_c;  // inclusive z range of the zero-banded compute set D
+  // z range over which the one-pass advection + diffusion kernel forms the advected vorticity on the core cells:
+  // the planes the vorticity update writes there, [g, pz - g - 1], plus the ghost plane next to a neighbouring
+  // rank (what that rank computes for its own edge plane, needed by the diffusion stencil of this rank's edge)
+  int za_lo, za_hi;
 };
 
 Geo make_geo(const smi_ctx* c) {
@@ -39,6 +43,8 @@ Geo make_geo(const smi_ctx* c) {
   // at a rank boundary the first / last interior plane is computed from exchanged ghosts.
   G.zlo_c = c->g + (c->phys_zlo ? 1 : 0);
   G.zhi_c = c->pz - c->g - 1 - (c->phys_zhi ? 1 : 0);
+  G.za_lo = c->g - (c->phys_zlo ? 0 : 1);
+  G.za_hi = c->pz - c->g - 1 + (c->phys_zhi ? 0 : 1);
   return G;
 }
 
@@ -641,7 +647,8 @@ constexpr int kFusedThreads = 1024;
 template <typename T>
 __global__ void __launch_bounds__(kFusedThreads) k_advect_diffuse(T* __restrict__ out, const T* __restrict__ vel,
                                                                  const T* __restrict__ vort, T pref, T cdiff, Geo G,
-                                                                 int zchunk, FusedShape S) {
+                                                                 int zchunk, FusedShape S, int chunk0,
+                                                                 int chunk_step) {
   extern __shared__ char smi_tile_smem[];
   T* lds = reinterpret_cast<T*>(smi_tile_smem);
   const Blk B = xcd_block<true>();
@@ -667,7 +674,9 @@ __global__ void __launch_bounds__(kFusedThreads) k_advect_diffuse(T* __restrict_
       mB |= (unsigned)((yf && xc) || (ye && xf)) << e;
     }
   }
-  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  // chunk of this workgroup: chunk0 + chunk_step * (position along grid y), so that one launch can cover a run of
+  // chunks (step 1) or the first and the last one (step = number of chunks - 1)
+  const int z0 = (chunk0 + chunk_step * B.y) * zchunk, z1 = min(z0 + zchunk, G.pz);
   auto plane_of = [&](int z) { return (long long)min(max(z, 0), G.pz - 1) * G.plane + q; };
   Vec3<T, 4> lu, lw;  // u and w of the plane two ahead, in flight
   Pack<T, 4> bPx, bPy, bCx, bCy, bCz, dummy;
@@ -702,7 +711,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_advect_diffuse(T* __restrict_
     if (lane_on) {
       // w* of plane k + 1
       const int j = k + 1;
-      const unsigned m = ((j >= 1 && j <= G.pz - 2) ? mB : 0u) | ((j >= G.g && j <= G.pz - G.g - 1) ? mA : 0u);
+      const unsigned m = ((j >= 1 && j <= G.pz - 2) ? mB : 0u) | ((j >= G.za_lo && j <= G.za_hi) ? mA : 0u);
       const T* tx = tb + off;
       const T* ty = tb + comp + off;
       const T* tz = tb + 2 * comp + off;
@@ -1552,14 +1561,20 @@ static int fused_zchunk(const smi_ctx* c, int tiles_per_plane) {
 }
 
 // out = advection update followed by the diffusion timestep of `vorticity`, in one pass (k_advect_diffuse).
-// *ran = 0 and nothing is launched when this context is not served by the fused kernel (several ranks: the
-// advected vorticity of the neighbour's edge planes would be needed; double precision: the LDS tiles do not fit;
-// unaligned arrays): the caller then runs the two operators one after the other.
+// *ran = 0 and nothing is launched when this context is not served by the fused kernel (double precision: the LDS
+// tiles do not fit; unaligned arrays; fewer than two ghost layers across ranks): the caller then runs the two
+// operators one after the other.
+// Across ranks the kernel needs u and w on BOTH ghost planes next to a neighbour (the advected vorticity of the
+// neighbour's edge plane is formed here from them, see Geo::za_lo), which one exchange of depth 2 delivers, in place
+// of the two exchanges of depth 1 of the two-pass path.  That exchange runs on the communication stream while the
+// chunks of planes that are out of reach of the ghost planes are already being computed; the first and the last
+// chunk follow once it has arrived.
 int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double pref_curl, double pref_diff,
                             int* ran) {
   *ran = 0;
   SMI_REQUIRE(out != velocity && out != vorticity, "advection-diffusion: output and input must not alias");
-  if (smi_multi_rank(c) || c->dtype != SMI_F32 || getenv("SMI_NO_FUSED_ADVECT_DIFFUSE")) return 0;
+  if (c->dtype != SMI_F32 || getenv("SMI_NO_FUSED_ADVECT_DIFFUSE")) return 0;
+  if (smi_multi_rank(c) && c->g < 2) return 0;
   if (!(vec_ok<float>(c, out, velocity) && vec_ok<float>(c, out, vorticity))) return 0;
   FusedShape S;
   if (!fused_shape<float>(c, S)) return 0;
@@ -1568,12 +1583,50 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   SMI_CHECK_HIP(hipFuncSetAttribute((const void*)k_advect_diffuse<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
   const int zchunk = fused_zchunk(c, S.ntx * S.nty);
-  dim3 grid(S.ntx * S.nty, (c->pz + zchunk - 1) / zchunk, 1);
-  SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
-  k_advect_diffuse<float><<<grid, kFusedThreads, lds_bytes, c->stream>>>((float*)out, (const float*)velocity,
-                                                                        (const float*)vorticity, (float)pref_curl,
-                                                                        (float)pref_diff, G, zchunk, S);
-  SMI_LAUNCH_CHECK();
+  const int nchunks = (c->pz + zchunk - 1) / zchunk;
+  auto launch = [&](int chunk0, int step, int count) {
+    dim3 grid(S.ntx * S.nty, count, 1);
+    k_advect_diffuse<float><<<grid, kFusedThreads, lds_bytes, c->stream>>>((float*)out, (const float*)velocity,
+                                                                          (const float*)vorticity, (float)pref_curl,
+                                                                          (float)pref_diff, G, zchunk, S, chunk0, step);
+  };
+  if (!smi_multi_rank(c)) {
+    SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
+    launch(0, 1, nchunks);
+    SMI_LAUNCH_CHECK();
+    *ran = 1;
+    return 0;
+  }
+  const int saved_depth = c->halo_depth;
+  c->halo_depth = c->g > 2 ? 2 : 0;  // two planes (0 = all g of them)
+  // a chunk reads planes z0 - 2 .. z1 + 1: only the first and the last one can reach a ghost plane when the chunks
+  // are at least g + 2 planes long
+  const bool overlap = !c->exchange_cb && nchunks >= 3 && zchunk >= c->g + 2;
+  auto exchange = [&]() -> int {
+    if (!overlap) return smi_halo_exchange2_impl(c, velocity, 3, vorticity, 3);
+    // No RCCL call may be issued on c->stream while this exchange is pending on the communication stream (one
+    // communicator, two streams): the launches below are plain kernels, and the stream waits for ev_b before
+    // anything else follows.
+    SMI_CHECK_HIP(hipEventRecord(c->ev_a, c->stream));
+    SMI_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_a, 0));
+    SMI_CHECK(smi_halo_exchange2_on(c, velocity, 3, vorticity, 3, c->comm_stream));
+    SMI_CHECK_HIP(hipEventRecord(c->ev_b, c->comm_stream));
+    return 0;
+  };
+  const int rc = exchange();
+  c->halo_depth = saved_depth;
+  SMI_CHECK(rc);
+  {
+    SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
+    if (overlap) {
+      launch(1, 1, nchunks - 2);
+      SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_b, 0));
+      launch(0, nchunks - 1, 2);
+    } else {
+      launch(0, 1, nchunks);
+    }
+    SMI_LAUNCH_CHECK();
+  }
   *ran = 1;
   return 0;
 }

@@ -29,8 +29,11 @@ real_t = np.float32
 flow_type = sys.argv[1] if len(sys.argv) > 1 else "navier_stokes"
 fused = (sys.argv[2] == "fused") if len(sys.argv) > 2 else True
 n = tuple(int(v) for v in sys.argv[3].split("x")) if len(sys.argv) > 3 else (32, 16, 32)
+with_filter = not (len(sys.argv) > 4 and sys.argv[4] == "nofilter")
 kw = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, flow_type=flow_type, real_t=real_t,
-          with_free_stream_flow=True, filter_vorticity=True, filter_setting_dict={"order": 1, "type": "multiplicative"})
+          with_free_stream_flow=True, filter_vorticity=with_filter)
+if with_filter:
+    kw["filter_setting_dict"] = {"order": 1, "type": "multiplicative"}
 gpu = UnboundedFlowSimulator3D(fused_step=fused, **kw)
 assert gpu.unbounded_poisson_solver.backend == "pruned"
 assert list(gpu.mpi_construct.local_grid_size) == [n[0] // size, n[1], n[2]]
