@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("nranks,flow_type,mode,grid", [
     (2, "navier_stokes", "fused", "32x16x32"),
     # without the vorticity filter: the one-pass advection + diffusion leaves its result in the buffer array and the
-    # simulator exchanges the two; slabs of 24 and of 12 planes (several z chunks per slab / a single one)
-    (2, "navier_stokes", "fused", "48x16x32 nofilter"),
-    (4, "navier_stokes_with_forcing", "fused", "48x16x64 nofilter"),
+    # simulator exchanges the two; slabs of 32 and of 16 planes (several z chunks per slab / a single one)
+    (2, "navier_stokes", "fused", "64x16x32 nofilter"),
+    (4, "navier_stokes_with_forcing", "fused", "64x32x64 nofilter"),
     (4, "navier_stokes", "unfused", "32x16x32"),
     (2, "navier_stokes_with_forcing", "fused", "32x16x32"),
     (4, "navier_stokes_with_forcing", "fused", "32x16x32"),
