@@ -28,10 +28,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 #   lower-bound model        : 165 S =  660 B  (pruned FFTs + per-phase fusion); the step-level
 #                              fraction is quoted on this one because the implementation
 #                              beats the first (its fraction on it exceeds 100 %)
-#   this implementation      : 102 S =  408 B  (advect 9 + diffuse 6 + 3 x Poisson 27 + curl 6)
+#   this implementation      :  96 S =  384 B  (advect + diffuse in one pass 9 + 3 x Poisson 27 + curl 6;
+#                              the two-pass form of double precision moves 102 S)
 ALG_BYTES_PER_POINT_STEP = 1692.0
 MIN_BYTES_PER_POINT_STEP = 660.0
-IMPL_BYTES_PER_POINT_STEP = 408.0
+IMPL_BYTES_PER_POINT_STEP = {"f32": 96 * 4.0, "f64": 102 * 8.0}
 # rocprofv3 --pmc counters of every hot kernel (tools/pmc_bench.sh + tools/make_counters_json.py); they are not
 # measured inside this run: the file records the hash of the library sources it was collected on, and its figures
 # are withheld when that differs from the sources in this tree
@@ -213,10 +214,10 @@ def main():
         "rccl_ranks": args.gpus if sim.ctx.transport == "rccl" else 0,
         "poisson_backend": sim.unbounded_poisson_solver.backend,
         # fraction of the HBM peak the step reaches, on the bytes this implementation moves by design
-        # (408 B per grid point and step in f32: advect 9 S + diffuse 6 S + 3 x Poisson 27 S + curl 6 S)
-        "step_bytes_model": f"implementation, {IMPL_BYTES_PER_POINT_STEP * (1 if args.dtype == 'f32' else 2):.0f} B per "
+        # (f32: advect + diffuse 9 S + 3 x Poisson 27 S + curl 6 S, S = 4 B per grid point)
+        "step_bytes_model": f"implementation, {IMPL_BYTES_PER_POINT_STEP[args.dtype]:.0f} B per "
                             "grid point per step",
-        "step_hbm_frac": IMPL_BYTES_PER_POINT_STEP * (1 if args.dtype == "f32" else 2) * per_gpu,
+        "step_hbm_frac": IMPL_BYTES_PER_POINT_STEP[args.dtype] * per_gpu,
         # the same with the HBM bytes the kernels were measured to move (sum over the counter file), when current
         "step_hbm_frac_measured": None,
         # two byte models of the survey, for reference: the reference's operator sequence with padded FFTs

@@ -50,7 +50,13 @@ int smi_device_count(int* count);
  * (utils/mpi_utils_3d.py:14-83, 118-139).  nz/ny/nx: LOCAL interior sizes of this
  * slab; rank/nranks: position in the z-slab decomposition (physical z boundaries
  * are rank 0's low face and rank nranks-1's high face; y and x faces are always
- * physical).  dtype: SMI_F32 / SMI_F64. */
+ * physical).  dtype: SMI_F32 / SMI_F64.
+ *
+ * Devices and threads: the create calls make `device` the calling thread's current HIP device; every other entry
+ * point launches on the context's own stream WITHOUT switching devices, and HIP binds a stream to the device it
+ * was created on.  The supported arrangement is the reference's: one process per GPU, one context per process,
+ * calls from the thread that created the context.  A process that holds contexts on several devices must make
+ * the context's device current (hipSetDevice) on the calling thread before each call. */
 int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost,
                    int rank, int nranks);
 int smi_ctx_destroy(smi_ctx* ctx);

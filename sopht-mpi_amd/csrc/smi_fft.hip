@@ -1271,6 +1271,12 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
   const size_t comp_bytes = peer_bytes * G.P;
   const bool overlap = !c->alltoall_cb;
   hipStream_t cstream = overlap ? s->comm_stream : c->stream;
+  // Invariant of the split: work on the communication stream is bracketed by events on BOTH sides.  A transpose
+  // starts only after `ready` (recorded on the compute stream behind the kernel that produced its input), and the
+  // compute stream waits for `done` before the kernel that consumes its output.  The last thing this function
+  // queues on the compute stream waits for the last `done`, so when it returns the communication stream holds
+  // nothing that the compute stream has not been ordered after: the caller may treat the solve as ordinary work on
+  // c->stream, and the next solve may reuse bufA / bufT / the events without further synchronisation.
   auto transpose = [&](int k, bool back, hipEvent_t ready, hipEvent_t done) -> int {
     char* a = (char*)s->bufA + (size_t)k * comp_bytes;
     char* t = (char*)s->bufT + (size_t)k * comp_bytes;

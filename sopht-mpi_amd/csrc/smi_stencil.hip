@@ -1327,8 +1327,8 @@ TiledLaunch tiled_launch(const smi_ctx* c, int ncomp_lds, int grid_z) {
   return t;
 }
 // The tiled kernels may need more than the default 64 KB of dynamic LDS (double precision).  The
-// attribute belongs to the current device's copy of the function, so it is set before every
-// launch rather than cached per process: a process may hold contexts on several devices.
+// attribute belongs to the current device's copy of the function and costs next to nothing to set,
+// so it is set before every launch rather than cached per process.
 template <typename F>
 int allow_lds(F fn) {
   SMI_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));

@@ -18,6 +18,7 @@ SLOTS = {  # profiler slot of the library -> kernel name prefix in the rocprofv3
     "fft_y_inv": "void k_fft_y_inv<",
     "fft_x_fwd": "void k_fft_x_fwd<",
     "fft_x_inv": "void k_fft_x_inv<",
+    "fused_advect_diffuse": "void k_advect_diffuse<",
     "fused_advect": "void k_advect_tiled<",
     "fused_diffuse": "void k_diffuse_tiled<",
     "curl": "void k_curl_tiled<",

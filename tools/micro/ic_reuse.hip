@@ -3,7 +3,8 @@
 // A producer kernel streams `bytes` into a buffer (plain or non-temporal stores), a consumer kernel
 // then reads the same range (plain or non-temporal loads).  Between the two nothing else runs.
 // The last rows read a buffer far larger than the cache in the same way (the HBM reference).
-// Build: hipcc --offload-arch=gfx950 -O3 tools/micro/ic_reuse.hip -o build/ic_reuse
+// Build: hipcc --offload-arch=gfx950 -O3 -Xclang -target-feature -Xclang -packed-fp32-ops tools/micro/ic_reuse.hip \
+//        -o build/ic_reuse
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
