@@ -228,6 +228,10 @@ class VirtualBoundaryForcingMPI:
             self.nearest_eul_grid_index_to_lag_grid = self.ctx.zeros((2, num_lag_nodes), np.int64)
             self.interp_weights = self.ctx.zeros(win, np.float64)
 
+    # True: gather and re-scatter the mismatch state on every call like the reference (:243-251), e.g. to keep the
+    # global mismatch arrays current at all times; the default does it only when a node changes slabs
+    resync_every_call = False
+
     def update_buffers(self, global_lag_grid_position_field):
         """:238-276: re-map nodes to slabs; re-scatter the mismatch state when ownership changed."""
         comm = self.mpi_lagrangian_field_communicator
@@ -237,7 +241,7 @@ class VirtualBoundaryForcingMPI:
         # sub-step of the body's own integrator) the reference's per-call gather of both fields is skipped, and
         # the global mismatch arrays are brought up to date on demand (sync_global_mismatch_fields).
         new_address = comm.owner_ranks_of(global_lag_grid_position_field)
-        if np.array_equal(new_address, comm.rank_address):
+        if np.array_equal(new_address, comm.rank_address) and not self.resync_every_call:
             return
         self.sync_global_mismatch_fields()   # with the ownership the local arrays were laid out for
         comm.adopt_owner_ranks(new_address)

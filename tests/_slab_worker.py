@@ -29,7 +29,10 @@ real_t = np.float32
 flow_type = sys.argv[1] if len(sys.argv) > 1 else "navier_stokes"
 fused = (sys.argv[2] == "fused") if len(sys.argv) > 2 else True
 n = tuple(int(v) for v in sys.argv[3].split("x")) if len(sys.argv) > 3 else (32, 16, 32)
-with_filter = not (len(sys.argv) > 4 and sys.argv[4] == "nofilter")
+with_filter = "nofilter" not in sys.argv[4:]
+# "resync": gather and re-scatter the mismatch state before every interaction, as the reference does on every call
+# (VirtualBoundaryForcingMPI.py:243-251); a timing aid, the results are the same
+resync_every_call = "resync" in sys.argv[4:]
 kw = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, flow_type=flow_type, real_t=real_t,
           with_free_stream_flow=True, filter_vorticity=with_filter)
 if with_filter:
@@ -80,6 +83,7 @@ for step in range(4):
             interactor.forcing_grid.reference_positions[...] = pos_now
         interactor.time_step(dt)
         t_host = time.perf_counter()
+        interactor.resync_every_call = resync_every_call
         interactor()
         interactor_ms.append(1e3 * (time.perf_counter() - t_host))
         ref.time_step(dt)
