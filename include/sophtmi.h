@@ -271,6 +271,14 @@ int smi_ib_spread_fused(smi_ctx* ctx, void* eul_forcing, const void* lag_forcing
 /* update_lag_grid_position_mismatch_field_via_euler_forward (:297-310) */
 int smi_ib_mismatch_step(smi_ctx* ctx, void* position_mismatch, const void* velocity_mismatch,
                          int64_t n, double dt);
+/* VirtualBoundaryForcingMPI.py:278-331 (compute_lag_grid_velocity_mismatch_field,
+ * compute_lag_grid_forcing_field): velocity_mismatch = flow_velocity - body_velocity,
+ * lag_forcing = stiffness * position_mismatch + damping * velocity_mismatch, on n = dim * nodes
+ * device-resident doubles.  The step-by-step (2D) interaction uses it; the fused 3D kernel has
+ * it built in. */
+int smi_ib_penalty_force(smi_ctx* ctx, void* lag_forcing, void* velocity_mismatch, const void* flow_velocity,
+                         const void* body_velocity, const void* position_mismatch, int64_t n,
+                         double stiffness, double damping);
 
 /* ---- fused flow step ---------------------------------------------------------------
  * One navier_stokes / navier_stokes_with_forcing step of UnboundedFlowSimulator3D

@@ -430,3 +430,30 @@ extern "C" int smi_ib_mismatch_step(smi_ctx* c, void* position_mismatch, const v
   SMI_LAUNCH_CHECK();
   return 0;
 }
+
+// VirtualBoundaryForcingMPI.py:278-331, the three pointwise kernels in one: velocity mismatch = interpolated flow
+// velocity - body velocity, force = k * position mismatch + c * velocity mismatch.  n = dim * nodes doubles.
+__global__ void __launch_bounds__(256) k_penalty_force(double* __restrict__ force, double* __restrict__ vel_mismatch,
+                                                       const double* __restrict__ flow_vel,
+                                                       const double* __restrict__ body_vel,
+                                                       const double* __restrict__ pos_mismatch, int64_t n, double k,
+                                                       double cdamp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double dv = flow_vel[i] - body_vel[i];
+  vel_mismatch[i] = dv;
+  force[i] = k * pos_mismatch[i] + cdamp * dv;
+}
+
+extern "C" int smi_ib_penalty_force(smi_ctx* c, void* lag_forcing, void* velocity_mismatch, const void* flow_velocity,
+                                    const void* body_velocity, const void* position_mismatch, int64_t n,
+                                    double stiffness, double damping) {
+  SMI_REQUIRE(c && lag_forcing && velocity_mismatch && flow_velocity && body_velocity && position_mismatch && n >= 0,
+              "smi_ib_penalty_force: bad argument");
+  if (n == 0) return 0;
+  k_penalty_force<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(
+      (double*)lag_forcing, (double*)velocity_mismatch, (const double*)flow_velocity, (const double*)body_velocity,
+      (const double*)position_mismatch, n, stiffness, damping);
+  SMI_LAUNCH_CHECK();
+  return 0;
+}

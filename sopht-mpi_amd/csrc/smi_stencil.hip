@@ -1599,9 +1599,10 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   }
   const int saved_depth = c->halo_depth;
   c->halo_depth = c->g > 2 ? 2 : 0;  // two planes (0 = all g of them)
-  // a chunk reads planes z0 - 2 .. z1 + 1: only the first and the last one can reach a ghost plane when the chunks
-  // are at least g + 2 planes long
-  const bool overlap = !c->exchange_cb && nchunks >= 3 && zchunk >= c->g + 2;
+  // a chunk reads planes z0 - 2 .. z1 + 1: only the first and the last one can reach a ghost plane when both of
+  // them are at least g + 2 planes long (the last one is the remainder of the division)
+  const int last_chunk = c->pz - (nchunks - 1) * zchunk;
+  const bool overlap = !c->exchange_cb && nchunks >= 3 && zchunk >= c->g + 2 && last_chunk >= c->g + 2;
   auto exchange = [&]() -> int {
     if (!overlap) return smi_halo_exchange2_impl(c, velocity, 3, vorticity, 3);
     // No RCCL call may be issued on c->stream while this exchange is pending on the communication stream (one

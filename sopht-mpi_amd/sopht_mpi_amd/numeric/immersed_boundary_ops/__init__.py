@@ -137,7 +137,7 @@ class EulerianLagrangianGridCommunicatorMPI2D:
 
 class VirtualBoundaryForcingMPI:
     """VirtualBoundaryForcingMPI.py:21-459.  3D as described below; 2D (one GPU) runs the
-    communicator's four kernels one after the other and forms the penalty force on the host.
+    communicator's four kernels one after the other and forms the penalty force with a fifth.
 
     Global Lagrangian arrays (``global_lag_grid_*``) are host numpy arrays owned by the master
     rank as in the reference; the ``local_lag_grid_*`` arrays of this slab's nodes live on the
@@ -304,12 +304,13 @@ class VirtualBoundaryForcingMPI:
             comm.eulerian_to_lagrangian_grid_interpolation_kernel(
                 self.local_lag_grid_flow_velocity_field, local_eul_grid_velocity_field, self.interp_weights,
                 self.nearest_eul_grid_index_to_lag_grid)
-            vmis = self.local_lag_grid_flow_velocity_field.get() - np.asarray(global_lag_grid_velocity_field)
-            forcing = (self.virtual_boundary_stiffness_coeff * self.local_lag_grid_position_mismatch_field.get()
-                       + self.virtual_boundary_damping_coeff * vmis)
-            self.local_lag_grid_velocity_mismatch_field.set(vmis)
-            self.local_lag_grid_forcing_field.set(forcing)
-            self.global_lag_grid_forcing_field[...] = forcing
+            call("smi_ib_penalty_force", self.ctx.handle, as_ptr(self.local_lag_grid_forcing_field),
+                 as_ptr(self.local_lag_grid_velocity_mismatch_field), as_ptr(self.local_lag_grid_flow_velocity_field),
+                 as_ptr(self.local_lag_grid_velocity_field), as_ptr(self.local_lag_grid_position_mismatch_field),
+                 self.grid_dim * self.local_num_lag_nodes, float(self.virtual_boundary_stiffness_coeff),
+                 float(self.virtual_boundary_damping_coeff))
+            if _download:
+                self._download_lag_grid_forcing()
             return
         call("smi_ib_forcing_fused", self.ctx.handle, as_ptr(self.local_lag_grid_forcing_field),
              as_ptr(self.local_lag_grid_velocity_mismatch_field), as_ptr(self.local_lag_grid_flow_velocity_field),
@@ -336,13 +337,14 @@ class VirtualBoundaryForcingMPI:
         """:408-429."""
         self.compute_interaction_force_on_lag_grid(
             local_eul_grid_velocity_field, global_lag_grid_position_field, global_lag_grid_velocity_field,
-            _download=self.grid_dim == 2,
+            _download=False,
         )
         comm = self.eul_lag_grid_communicator
         if self.grid_dim == 2:
             comm.lagrangian_to_eulerian_grid_interpolation_kernel(
                 local_eul_grid_forcing_field, self.local_lag_grid_forcing_field, self.interp_weights,
                 self.nearest_eul_grid_index_to_lag_grid)
+            self._download_lag_grid_forcing()  # after the spread has been queued
             return
         # the spread states its footprint (the 4^3 windows of the nodes), so the record of where the forcing
         # field is non-zero survives and the flow step can skip the rest of the grid
