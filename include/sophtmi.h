@@ -170,6 +170,11 @@ int smi_penalise_boundary(smi_ctx* ctx, void* field, int ncomp, int width, const
 /* gen_laplacian_filter_mpi_kernel_3d, laplacian_filter_mpi_3d.py:14-421 */
 int smi_laplacian_filter(smi_ctx* ctx, void* field, int ncomp, void* filter_flux_buffer,
                          void* field_buffer, int order, int filter_type);
+/* The same with filter_flux_buffer_boundary_width (laplacian_filter_mpi_3d.py:23, 110-143): the filter
+ * flux is cleared on the ghost_size + boundary_width layers next to every physical face
+ * (smi_laplacian_filter is boundary_width = 1, the reference's default). */
+int smi_laplacian_filter_w(smi_ctx* ctx, void* field, int ncomp, void* filter_flux_buffer,
+                           void* field_buffer, int order, int filter_type, int boundary_width);
 /* gen_advection_timestep_euler_forward_conservative_eno3_pyst_mpi_kernel_3d,
  * advection_timestep_mpi_3d.py:12-95 (+ advection_flux_mpi_3d.py:8-195) */
 int smi_advection_timestep_eno3(smi_ctx* ctx, void* field, void* flux, void* velocity,

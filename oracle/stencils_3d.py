@@ -253,24 +253,26 @@ def _filter_pass(axis, flux_buf, field_buf, g, exchange=None):
 
 
 def laplacian_filter(field, flux_buf, field_buf, order, g, filter_type="multiplicative",
-                     phys=ALL_PHYS, exchange=None):
-    """laplacian_filter_mpi_3d.py:267-385 (scalar, in place). ``exchange(arr)`` ghosts one scalar."""
+                     phys=ALL_PHYS, exchange=None, boundary_width=1):
+    """laplacian_filter_mpi_3d.py:267-385 (scalar, in place). ``exchange(arr)`` ghosts one scalar;
+    ``boundary_width`` is filter_flux_buffer_boundary_width (:110-143)."""
+    w = boundary_width
     if filter_type == "multiplicative":
-        zero_physical_bands(flux_buf, g, 1, phys)
+        zero_physical_bands(flux_buf, g, w, phys)
         field_buf[...] = field
         for _ in range(order):
             for axis in (0, 1, 2):  # x, y, z
                 _filter_pass(axis, flux_buf, field_buf, g, exchange)
-                zero_physical_bands(flux_buf, g, 1, phys)
+                zero_physical_bands(flux_buf, g, w, phys)
                 field_buf[...] = flux_buf
         field[...] = field - flux_buf
     elif filter_type == "convolution":
-        zero_physical_bands(flux_buf, g, 1, phys)
+        zero_physical_bands(flux_buf, g, w, phys)
         for axis in (0, 1, 2):
             field_buf[...] = field
             for _ in range(order):
                 _filter_pass(axis, flux_buf, field_buf, g, exchange)
-                zero_physical_bands(flux_buf, g, 1, phys)
+                zero_physical_bands(flux_buf, g, w, phys)
                 field_buf[...] = flux_buf
             field[...] = field - flux_buf
     else:
@@ -278,9 +280,9 @@ def laplacian_filter(field, flux_buf, field_buf, order, g, filter_type="multipli
 
 
 def vector_laplacian_filter(vfield, flux_buf, field_buf, order, g, filter_type="multiplicative",
-                            phys=ALL_PHYS, exchange=None):
+                            phys=ALL_PHYS, exchange=None, boundary_width=1):
     for c in range(3):
-        laplacian_filter(vfield[c], flux_buf, field_buf, order, g, filter_type, phys, exchange)
+        laplacian_filter(vfield[c], flux_buf, field_buf, order, g, filter_type, phys, exchange, boundary_width)
 
 
 # ENO3 advection (body lives in ``sopht``; parity unpinned) ---------------------------

@@ -1735,12 +1735,26 @@ int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp) {
 
 extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* filter_flux_buffer,
                                     void* field_buffer, int order, int filter_type) {
+  return smi_laplacian_filter_w(c, field, ncomp, filter_flux_buffer, field_buffer, order, filter_type, 1);
+}
+
+extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* filter_flux_buffer,
+                                      void* field_buffer, int order, int filter_type, int boundary_width) {
   SMI_REQUIRE(c && field && filter_flux_buffer && field_buffer && ncomp >= 1, "smi_laplacian_filter: bad argument");
   SMI_REQUIRE(order >= 0, "Invalid filter order");
   SMI_REQUIRE(filter_type == SMI_FILTER_MULTIPLICATIVE || filter_type == SMI_FILTER_CONVOLUTION,
               "Invalid filter type");
+  SMI_REQUIRE(boundary_width >= 1, "Invalid value for filter flux buffer boundary zone");
+  const int w = boundary_width;
+  SMI_REQUIRE(c->g + w < c->py - c->g - w && c->g + w < c->px - c->g - w && c->g + w < c->pz - c->g - w,
+              "smi_laplacian_filter: boundary width %d leaves no cells", w);
   Geo G = make_geo(c);
-  if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1) {
+  // the filter flux lives on the cells at least g + w away from a physical face (laplacian_filter_mpi_3d.py:110-143);
+  // the directional passes take their x / y limits from G.g and their z limits from zlo_c / zhi_c
+  G.g = c->g + w - 1;
+  G.zlo_c = c->g + (c->phys_zlo ? w : 0);
+  G.zhi_c = c->pz - c->g - 1 - (c->phys_zhi ? w : 0);
+  if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1 && w == 1) {
     // one fused pass into the scratch field, then back (the scratch fields hold one component)
     const size_t stride = c->vol * smi_elem_size(c);
     for (int k = 0; k < ncomp; ++k) {
@@ -1762,7 +1776,7 @@ extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* fi
       if (filter_type == SMI_FILTER_MULTIPLICATIVE) {
         if (order == 0) {
           // degenerate: field -= (stale flux buffer with its physical bands cleared)
-          k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + 1, c->phys_zlo, c->phys_zhi);
+          k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi);
           SMI_LAUNCH_CHECK();
           SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
           continue;
@@ -1779,7 +1793,7 @@ extern "C" int smi_laplacian_filter(smi_ctx* c, void* field, int ncomp, void* fi
       } else {
         for (int axis = 0; axis < 3; ++axis) {
           if (order == 0) {
-            k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + 1, c->phys_zlo, c->phys_zhi);
+            k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi);
             SMI_LAUNCH_CHECK();
             SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
             continue;

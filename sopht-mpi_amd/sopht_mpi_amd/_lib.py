@@ -68,6 +68,7 @@ SIGNATURES = {
     "smi_divergence": [_p, _p, _p, _d],
     "smi_penalise_boundary": [_p, _p, _i, _i, _dp, _dp],
     "smi_laplacian_filter": [_p, _p, _i, _p, _p, _i, _i],
+    "smi_laplacian_filter_w": [_p, _p, _i, _p, _p, _i, _i, _i],
     "smi_advection_timestep_eno3": [_p, _p, _p, _p, _d, _i],
     "smi_advection_flux_eno3": [_p, _p, _p, _p, _d],
     "smi_rotational_advection_update": [_p, _p, _p, _p, _d],

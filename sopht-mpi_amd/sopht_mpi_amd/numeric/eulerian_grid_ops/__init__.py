@@ -218,8 +218,7 @@ def gen_laplacian_filter_mpi_kernel_3d(mpi_construct, ghost_exchange_communicato
         raise ValueError("Invalid filter order")
     if filter_flux_buffer_boundary_width <= 0 or not isinstance(filter_flux_buffer_boundary_width, (int, np.integer)):
         raise ValueError("Invalid value for filter flux buffer boundary zone")
-    if filter_flux_buffer_boundary_width != 1:
-        raise NotImplementedError("only filter_flux_buffer_boundary_width=1 (the reference default) is supported")
+    width = int(filter_flux_buffer_boundary_width)
     types = {"multiplicative": _lib.SMI_FILTER_MULTIPLICATIVE, "convolution": _lib.SMI_FILTER_CONVOLUTION}
     if filter_type not in types:
         raise ValueError("Invalid filter type")
@@ -231,15 +230,15 @@ def gen_laplacian_filter_mpi_kernel_3d(mpi_construct, ghost_exchange_communicato
     if field_type == "scalar":
 
         def scalar_field_filter_mpi_kernel_3d(scalar_field):
-            call("smi_laplacian_filter", ctx.handle, as_ptr(scalar_field), 1, as_ptr(filter_flux_buffer),
-                 as_ptr(field_buffer), int(filter_order), ftype)
+            call("smi_laplacian_filter_w", ctx.handle, as_ptr(scalar_field), 1, as_ptr(filter_flux_buffer),
+                 as_ptr(field_buffer), int(filter_order), ftype, width)
 
         fn = scalar_field_filter_mpi_kernel_3d
     else:
 
         def vector_field_filter_kernel_3d(vector_field):
-            call("smi_laplacian_filter", ctx.handle, as_ptr(vector_field), 3, as_ptr(filter_flux_buffer),
-                 as_ptr(field_buffer), int(filter_order), ftype)
+            call("smi_laplacian_filter_w", ctx.handle, as_ptr(vector_field), 3, as_ptr(filter_flux_buffer),
+                 as_ptr(field_buffer), int(filter_order), ftype, width)
 
         fn = vector_field_filter_kernel_3d
     return _support(gen_laplacian_filter_mpi_kernel_3d, fn, 1, ghost_exchange_communicator)

@@ -175,6 +175,33 @@ def test_laplacian_filter(smi, shape, g, order, filter_type, real_t):
     assert_close(df.get(), want, real_t, what="filter")
 
 
+@pytest.mark.parametrize("filter_type", ["multiplicative", "convolution"])
+@pytest.mark.parametrize("order,width", [(1, 2), (2, 2), (1, 3), (0, 2)])
+def test_laplacian_filter_boundary_width(smi, order, width, filter_type):
+    """filter_flux_buffer_boundary_width other than the default 1 (laplacian_filter_mpi_3d.py:110-143), through the
+    generator a simulation script would call."""
+    from sopht_mpi_amd.numeric.eulerian_grid_ops import gen_laplacian_filter_mpi_kernel_3d
+    from sopht_mpi_amd.utils import MPIConstruct3D, MPIGhostCommunicator3D
+
+    real_t, shape, g = np.float32, (12, 16, 20), 2
+    rng = np.random.default_rng(15)
+    construct = MPIConstruct3D(*shape, real_t=real_t)
+    ghost = MPIGhostCommunicator3D(ghost_size=g, mpi_construct=construct)
+    ctx = ghost.ctx
+    f = rand_field(rng, (3,) + ctx.padded_shape, real_t)
+    flux0 = rand_field(rng, ctx.padded_shape, real_t)
+    df, dflux, dbuf = ctx.from_numpy(f), ctx.from_numpy(flux0), ctx.from_numpy(rand_field(rng, ctx.padded_shape, real_t))
+    apply = gen_laplacian_filter_mpi_kernel_3d(construct, ghost, order, dflux, dbuf, real_t, field_type="vector",
+                                               filter_type=filter_type, filter_flux_buffer_boundary_width=width)
+    apply(vector_field=df)
+    want = f.copy()
+    st.vector_laplacian_filter(want, flux0.copy(), np.zeros(ctx.padded_shape, real_t), order, g, filter_type,
+                               boundary_width=width)
+    assert_close(df.get(), want, real_t, what="filter with boundary width")
+    with pytest.raises(ValueError):
+        gen_laplacian_filter_mpi_kernel_3d(construct, ghost, 1, dflux, dbuf, real_t, filter_flux_buffer_boundary_width=0)
+
+
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
 def test_reductions(smi, real_t):
     rng = np.random.default_rng(6)
