@@ -285,6 +285,21 @@ int smi_ib_penalty_force(smi_ctx* ctx, void* lag_forcing, void* velocity_mismatc
                          const void* body_velocity, const void* position_mismatch, int64_t n,
                          double stiffness, double damping);
 
+/* Forcing grids of framed bodies formed on the device (replaces the host arithmetic of sopht's
+ * SphereForcingGrid / CosseratRodSurfaceForcingGrid compute_lag_grid_position_field,
+ * compute_lag_grid_velocity_field and transfer_forcing_from_grid_to_body; call sites
+ * immersed_body_flow_interaction_mpi.py:138-144, 171-175).  A node belongs to one frame (the sphere;
+ * a rod element): position = centre + Q^T (scale * local offset), velocity = v + (Q^T omega) x arm.
+ * frames: n_frames records of 19 doubles on the device - centre (3), directors row by row (9),
+ * velocity (3), angular velocity in the material frame (3), scale (1).  local_offsets, positions,
+ * velocities, arms: (3, m) doubles; frame_of_node: m int32. */
+int smi_ib_frame_nodes(smi_ctx* ctx, void* positions, void* velocities, void* arms, const void* local_offsets,
+                       const void* frame_of_node, const void* frames, int n_frames, int64_t m);
+/* loads[6 e .. 6 e + 5] = sum over the nodes of frame e of (force, arm x force), lab frame; the nodes of
+ * a frame are contiguous, frame_start holds n_frames + 1 int32 offsets.  Reproducible (fixed order). */
+int smi_ib_frame_loads(smi_ctx* ctx, void* loads, const void* lag_forcing, const void* arms,
+                       const void* frame_start, int n_frames, int64_t m);
+
 /* ---- fused flow step ---------------------------------------------------------------
  * One navier_stokes / navier_stokes_with_forcing step of UnboundedFlowSimulator3D
  * (flow_simulators_mpi_3d.py:395-424) with fused kernels.  forcing may be NULL

@@ -457,3 +457,93 @@ extern "C" int smi_ib_penalty_force(smi_ctx* c, void* lag_forcing, void* velocit
   SMI_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- forcing grids of framed bodies on the device
+// A rigid sphere, or the surface rings of a Cosserat rod, is a set of nodes each tied to one FRAME (the sphere; a rod
+// element): node = centre + Q^T (scale * local offset), velocity = v + (Q^T omega) x arm.  The host sends the frames
+// (a few doubles per element) and the device forms the (3, M) node arrays where the interaction kernels read them,
+// instead of the host forming them in numpy and uploading 6 M doubles per interaction.
+// Frame record, 19 doubles: centre (3), directors Q row by row (9; rows = material axes in lab coordinates, the
+// PyElastica convention), velocity of the centre (3), angular velocity in the material frame (3), scale (1).
+constexpr int kFrameDoubles = 19;
+
+__global__ void __launch_bounds__(256) k_frame_nodes(double* __restrict__ pos, double* __restrict__ vel,
+                                                     double* __restrict__ arm, const double* __restrict__ local,
+                                                     const int* __restrict__ frame_of_node,
+                                                     const double* __restrict__ frames, int64_t m) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= m) return;
+  const double* F = frames + (int64_t)kFrameDoubles * frame_of_node[n];
+  const double s = F[18];
+  const double l0 = s * local[n], l1 = s * local[m + n], l2 = s * local[2 * m + n];
+  double a[3], w[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    a[i] = F[3 + i] * l0 + F[6 + i] * l1 + F[9 + i] * l2;             // Q^T l
+    w[i] = F[3 + i] * F[15] + F[6 + i] * F[16] + F[9 + i] * F[17];    // Q^T omega
+  }
+  pos[n] = F[0] + a[0];
+  pos[m + n] = F[1] + a[1];
+  pos[2 * m + n] = F[2] + a[2];
+  vel[n] = F[12] + (w[1] * a[2] - w[2] * a[1]);
+  vel[m + n] = F[13] + (w[2] * a[0] - w[0] * a[2]);
+  vel[2 * m + n] = F[14] + (w[0] * a[1] - w[1] * a[0]);
+  arm[n] = a[0];
+  arm[m + n] = a[1];
+  arm[2 * m + n] = a[2];
+}
+
+extern "C" int smi_ib_frame_nodes(smi_ctx* c, void* positions, void* velocities, void* arms, const void* local_offsets,
+                                  const void* frame_of_node, const void* frames, int n_frames, int64_t m) {
+  SMI_REQUIRE(c && positions && velocities && arms && local_offsets && frame_of_node && frames && n_frames >= 1 &&
+                  m >= 0,
+              "smi_ib_frame_nodes: bad argument");
+  if (m == 0) return 0;
+  k_frame_nodes<<<(int)((m + 255) / 256), 256, 0, c->stream>>>((double*)positions, (double*)velocities, (double*)arms,
+                                                               (const double*)local_offsets, (const int*)frame_of_node,
+                                                               (const double*)frames, m);
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// Per frame: sum of the node forces and of arm x force (lab frame), six doubles.  One workgroup per frame walks the
+// frame's nodes (contiguous: frame_start[e] .. frame_start[e + 1] - 1) and reduces in a fixed order, so the result is
+// reproducible.  transfer_forcing_from_grid_to_body of the forcing grids is built from these sums on the host.
+__global__ void __launch_bounds__(256) k_frame_loads(double* __restrict__ loads, const double* __restrict__ force,
+                                                     const double* __restrict__ arm,
+                                                     const int* __restrict__ frame_start, int64_t m) {
+  __shared__ double part[6][256];
+  const int e = blockIdx.x, t = threadIdx.x;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int n = frame_start[e] + t; n < frame_start[e + 1]; n += 256) {
+    const double f0 = force[n], f1 = force[m + n], f2 = force[2 * m + n];
+    const double a0 = arm[n], a1 = arm[m + n], a2 = arm[2 * m + n];
+    acc[0] += f0;
+    acc[1] += f1;
+    acc[2] += f2;
+    acc[3] += a1 * f2 - a2 * f1;
+    acc[4] += a2 * f0 - a0 * f2;
+    acc[5] += a0 * f1 - a1 * f0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) part[k][t] = acc[k];
+  __syncthreads();
+  for (int half = 128; half >= 1; half >>= 1) {
+    if (t < half) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) part[k][t] += part[k][t + half];
+    }
+    __syncthreads();
+  }
+  if (t < 6) loads[6 * e + t] = part[t][0];
+}
+
+extern "C" int smi_ib_frame_loads(smi_ctx* c, void* loads, const void* lag_forcing, const void* arms,
+                                  const void* frame_start, int n_frames, int64_t m) {
+  SMI_REQUIRE(c && loads && lag_forcing && arms && frame_start && n_frames >= 1 && m >= 0,
+              "smi_ib_frame_loads: bad argument");
+  k_frame_loads<<<n_frames, 256, 0, c->stream>>>((double*)loads, (const double*)lag_forcing, (const double*)arms,
+                                                 (const int*)frame_start, m);
+  SMI_LAUNCH_CHECK();
+  return 0;
+}

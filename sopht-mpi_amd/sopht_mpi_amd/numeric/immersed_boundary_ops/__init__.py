@@ -207,7 +207,18 @@ class VirtualBoundaryForcingMPI:
         shape = (self.grid_dim, self.global_num_lag_nodes)
         self.global_lag_grid_position_mismatch_field = np.zeros(shape, dtype=np.float64)
         self.global_lag_grid_velocity_mismatch_field = np.zeros(shape, dtype=np.float64)
-        self.global_lag_grid_forcing_field = np.zeros(shape, dtype=np.float64)
+        self._global_lag_grid_forcing_field = np.zeros(shape, dtype=np.float64)
+        self._forcing_on_device_is_newer = False
+
+    @property
+    def global_lag_grid_forcing_field(self):
+        """Host (dim, M) array of the Lagrangian forcing (the master rank's, as in the reference).  On a single rank
+        the copy from the device is made when somebody reads the array, not after every interaction: that copy is a
+        synchronisation point, and a fixed or prescribed body never looks at the node forces."""
+        if self._forcing_on_device_is_newer:
+            self._forcing_on_device_is_newer = False
+            self._global_lag_grid_forcing_field[...] = self.local_lag_grid_forcing_field.get()
+        return self._global_lag_grid_forcing_field
 
     def _init_local_buffers(self, num_lag_nodes):
         """:201-236, device resident.  Support / weights arrays are not materialised by the
@@ -288,12 +299,16 @@ class VirtualBoundaryForcingMPI:
         """:333-406.  ``_download=False`` (internal): the caller fetches the forces itself, after it has
         queued the kernels that follow, so that the device does not idle during the copy."""
         multi = self.mpi_construct.size > 1
-        if not self.assume_data_locality and multi:
-            self.update_buffers(global_lag_grid_position_field)
-        elif not self.assume_data_locality:
-            # one slab owns every node: only the inside-the-domain check of the mapping remains
-            self.mpi_lagrangian_field_communicator._compute_lag_nodes_rank_address(global_lag_grid_position_field)
-        self._upload_lagrangian_state(global_lag_grid_position_field, global_lag_grid_velocity_field)
+        if isinstance(global_lag_grid_position_field, DeviceResidentNodes):
+            # the node arrays are on the device already (a framed forcing grid formed them there): no upload
+            self._check_inside_domain(global_lag_grid_position_field)
+        else:
+            if not self.assume_data_locality and multi:
+                self.update_buffers(global_lag_grid_position_field)
+            elif not self.assume_data_locality:
+                # one slab owns every node: only the inside-the-domain check of the mapping remains
+                self.mpi_lagrangian_field_communicator._compute_lag_nodes_rank_address(global_lag_grid_position_field)
+            self._upload_lagrangian_state(global_lag_grid_position_field, global_lag_grid_velocity_field)
         comm = self.eul_lag_grid_communicator
         if self.grid_dim == 2:
             # :360-397 step by step: support and index, weights, E -> L velocity, mismatch, penalty force
@@ -323,13 +338,26 @@ class VirtualBoundaryForcingMPI:
             self._download_lag_grid_forcing()
 
     def _download_lag_grid_forcing(self):
-        """Gather of the Lagrangian forcing to the master rank (:402-406)."""
+        """Gather of the Lagrangian forcing to the master rank (:402-406): a collective across ranks, on demand
+        (see ``global_lag_grid_forcing_field``) on one."""
         if not self.assume_data_locality and self.mpi_construct.size > 1:
             self.mpi_lagrangian_field_communicator.gather_local_field(
-                self.global_lag_grid_forcing_field, self.local_lag_grid_forcing_field.get()
+                self._global_lag_grid_forcing_field, self.local_lag_grid_forcing_field.get()
             )
         else:
-            self.global_lag_grid_forcing_field[...] = self.local_lag_grid_forcing_field.get()
+            self._forcing_on_device_is_newer = True
+
+    def _check_inside_domain(self, nodes):
+        """The reference stops when a node leaves the Eulerian domain (utils/mpi_utils_3d.py:1371-1379).  With the
+        nodes on the device the box around them is checked; only when the box sticks out are the nodes fetched."""
+        comm = self.mpi_lagrangian_field_communicator if not self.assume_data_locality else None
+        if comm is None:
+            return
+        extent = comm.eul_subblock_dx[::-1] * np.asarray(self.mpi_construct.grid_topology)[::-1]   # x, y, z
+        lo, hi = nodes.lo - comm.eul_grid_coord_shift, nodes.hi - comm.eul_grid_coord_shift
+        if np.all(hi < extent) and lo[2] >= 0:
+            return
+        comm._compute_lag_nodes_rank_address(self.local_lag_grid_position_field.get())
 
     def compute_interaction_force_on_eul_and_lag_grid(self, local_eul_grid_forcing_field,
                                                       local_eul_grid_velocity_field, global_lag_grid_position_field,
@@ -370,10 +398,15 @@ class VirtualBoundaryForcingMPI:
         (several ranks: the owner map decides which nodes are local)."""
         if self.mpi_construct.size > 1 or self.grid_dim != 3:
             return None
-        pos = np.asarray(global_lag_grid_position_field, dtype=np.float64)
+        comm = self.eul_lag_grid_communicator
+        if isinstance(global_lag_grid_position_field, DeviceResidentNodes):
+            if global_lag_grid_position_field.num_nodes == 0:
+                return ()
+            pos = np.stack((global_lag_grid_position_field.lo, global_lag_grid_position_field.hi), axis=1)
+        else:
+            pos = np.asarray(global_lag_grid_position_field, dtype=np.float64)
         if pos.shape[-1] == 0:
             return ()
-        comm = self.eul_lag_grid_communicator
         idx = np.floor((pos - comm.coord_shift) / comm.dx).astype(np.int64) + self.ghost_size
         # one more cell on either side: the device floors the same quotient in its own arithmetic
         lo, hi = idx.min(axis=1) - 2, idx.max(axis=1) + 3
@@ -400,5 +433,16 @@ class VirtualBoundaryForcingMPI:
         self.time += dt
 
 
-__all__ = ["EulerianLagrangianGridCommunicatorMPI2D", "EulerianLagrangianGridCommunicatorMPI3D",
+class DeviceResidentNodes:
+    """Stands in for the host (3, M) position / velocity arrays of an interaction whose node arrays are on the
+    device already (a framed forcing grid formed them there): all the host needs is a box, in physical
+    coordinates (x, y, z), that holds every node."""
+
+    def __init__(self, lo, hi, num_nodes):
+        self.lo, self.hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+        self.num_nodes = int(num_nodes)
+        self.shape = (3, self.num_nodes)
+
+
+__all__ = ["DeviceResidentNodes", "EulerianLagrangianGridCommunicatorMPI2D", "EulerianLagrangianGridCommunicatorMPI3D",
            "VirtualBoundaryForcingMPI"]

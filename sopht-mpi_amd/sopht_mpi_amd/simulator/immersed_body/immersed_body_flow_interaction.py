@@ -9,10 +9,12 @@ penalty force -> spreading; ``compute_flow_forces_and_torques`` stops after the 
 the body, which is what a rod's time integrator asks for on every sub-step.
 """
 import logging
+import os
 
 import numpy as np
 
 from ...numeric.immersed_boundary_ops import VirtualBoundaryForcingMPI
+from .forcing_grids import FramedForcingGrid
 from .immersed_body_forcing_grid import EmptyForcingGrid
 
 logger = logging.getLogger("sopht_mpi_amd")
@@ -61,6 +63,15 @@ class ImmersedBodyFlowInteractionMPI(VirtualBoundaryForcingMPI):
             start_time=start_time, master_rank=self.master_rank, global_lag_grid_position_field=nodes,
             assume_data_locality=assume_data_locality, interp_kernel_type=interp_kernel_type,
         )
+        # On one rank a framed forcing grid (sphere, rod surface) forms its node arrays on the device, straight into
+        # the arrays the interaction kernels read: a few doubles per frame cross PCIe instead of 6 M per call, and
+        # the host does no per-node arithmetic.  SOPHT_MI_HOST_FORCING_GRID=1 keeps the host path.
+        self.nodes_on_device = (mpi_construct.size == 1 and grid_dim == 3
+                                and isinstance(self.forcing_grid, FramedForcingGrid)
+                                and os.environ.get("SOPHT_MI_HOST_FORCING_GRID", "0") in ("", "0"))
+        if self.nodes_on_device:
+            self.forcing_grid.attach_device(self.ctx, self.local_lag_grid_position_field,
+                                            self.local_lag_grid_velocity_field)
         self.auto_ghosting = bool(auto_ghosting)
         if not self.auto_ghosting:
             logger.warning("Auto ghosting of velocity field is disabled for interactor. "
@@ -74,6 +85,10 @@ class ImmersedBodyFlowInteractionMPI(VirtualBoundaryForcingMPI):
         if self.auto_ghosting:
             self.mpi_ghost_exchange_communicator.exchange_vector_field_init(self.eul_grid_velocity_field)
             self.mpi_ghost_exchange_communicator.exchange_finalise()
+        if self.nodes_on_device:
+            nodes = self.forcing_grid.update_device_nodes()
+            return dict(local_eul_grid_velocity_field=self.eul_grid_velocity_field,
+                        global_lag_grid_position_field=nodes, global_lag_grid_velocity_field=nodes)
         self.forcing_grid.compute_lag_grid_position_field()
         self.forcing_grid.compute_lag_grid_velocity_field()
         return dict(local_eul_grid_velocity_field=self.eul_grid_velocity_field,
@@ -93,6 +108,11 @@ class ImmersedBodyFlowInteractionMPI(VirtualBoundaryForcingMPI):
     def compute_flow_forces_and_torques(self):
         """Node forces -> loads on the body, in ``body_flow_forces`` / ``body_flow_torques`` (:168-175)."""
         self.compute_interaction_on_lag_grid()
+        if self.nodes_on_device:
+            # per-frame sums on the device: 6 doubles per frame come back instead of 3 per node
+            self.forcing_grid.transfer_forcing_from_device(self.body_flow_forces, self.body_flow_torques,
+                                                           self.local_lag_grid_forcing_field)
+            return
         self.forcing_grid.transfer_forcing_from_grid_to_body(
             body_flow_forces=self.body_flow_forces, body_flow_torques=self.body_flow_torques,
             lag_grid_forcing_field=self.global_lag_grid_forcing_field)

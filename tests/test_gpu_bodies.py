@@ -136,6 +136,70 @@ def test_flow_past_rod_reduced(smi):
     assert np.any(interactor.body_flow_torques != 0)
 
 
+@pytest.mark.parametrize("body", ["sphere", "rod"])
+def test_nodes_formed_on_the_device_match_the_host_grid(smi, body, monkeypatch):
+    """A framed forcing grid forms its node arrays on the device (smi_ib_frame_nodes) and reduces the node forces to
+    body loads there (smi_ib_frame_loads); the host methods of the same grid class are the check: identical
+    kinematics for a translating, spinning body, and the same loads from the same interaction."""
+    from sopht_mpi_amd.simulator import (CosseratRodFlowInteraction, RigidBodyFlowInteractionMPI,
+                                         UnboundedFlowSimulator3D)
+    from sopht_mpi_amd.simulator.immersed_body.forcing_grids import (CosseratRodSurfaceForcingGrid, RigidSphereBody,
+                                                                     SphereForcingGrid, StraightRodBody)
+
+    real_t, n = np.float32, 48
+    sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=1e-2,
+                                   flow_type="navier_stokes_with_forcing", real_t=real_t, with_free_stream_flow=True)
+    sim.ctx.set_ordered_spread(True)
+    rng = np.random.default_rng(21)
+    sim.velocity_field[...] = rng.normal(size=sim.velocity_field.shape).astype(real_t)
+    th = 0.4
+    spin = np.array([[np.cos(th), np.sin(th), 0.0], [-np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+
+    def make(host):
+        monkeypatch.setenv("SOPHT_MI_HOST_FORCING_GRID", "1" if host else "0")
+        forcing = sim.ctx.field(3)
+        common = dict(mpi_construct=sim.mpi_construct, mpi_ghost_exchange_communicator=sim.mpi_ghost_exchange_communicator,
+                      eul_grid_forcing_field=forcing, eul_grid_velocity_field=sim.velocity_field,
+                      virtual_boundary_stiffness_coeff=-5e4, virtual_boundary_damping_coeff=-2e1, dx=sim.dx, grid_dim=3)
+        if body == "sphere":
+            b = RigidSphereBody(center=(0.45, 0.5, 0.55), base_radius=0.2)
+            b.velocity_collection[:, 0] = (0.3, -0.1, 0.2)
+            b.omega_collection[:, 0] = (0.5, 1.5, -0.7)
+            b.director_collection[:, :, 0] = spin
+            it = RigidBodyFlowInteractionMPI(rigid_body=b, forcing_grid_cls=SphereForcingGrid,
+                                             num_forcing_points_along_equator=40, **common)
+        else:
+            b = StraightRodBody(n_elements=24, start=(0.2, 0.5, 0.45), direction=(1.0, 0.2, 0.0), normal=(0.0, 0.0, 1.0),
+                                base_length=0.6, base_radius=0.04)
+            b.radius = b.radius * np.linspace(1.0, 0.6, b.n_elems)       # tapered: fewer points on thin elements
+            b.velocity_collection[...] = rng.normal(size=b.velocity_collection.shape) * 0.2
+            b.omega_collection[...] = np.linspace(-1, 1, b.n_elems) * np.array([[0.5], [1.0], [2.0]])
+            it = CosseratRodFlowInteraction(cosserat_rod=b, forcing_grid_cls=CosseratRodSurfaceForcingGrid,
+                                            surface_grid_density_for_largest_element=12, **common)
+        return it, forcing
+
+    rng = np.random.default_rng(22)
+    dev, f_dev = make(host=False)
+    rng = np.random.default_rng(22)
+    host, f_host = make(host=True)
+    assert dev.nodes_on_device and not host.nodes_on_device
+    for cycle in range(2):
+        for it in (dev, host):
+            it.compute_flow_forces_and_torques()
+            it.time_step(1e-3)
+            it()
+        gd, gh = dev.forcing_grid, host.forcing_grid
+        scale = np.abs(gh.position_field).max()
+        assert np.abs(gd.position_field - gh.position_field).max() <= 4e-16 * scale
+        assert np.abs(gd.velocity_field - gh.velocity_field).max() <= 1e-15 * max(np.abs(gh.velocity_field).max(), 1.0)
+        assert_close(dev.global_lag_grid_forcing_field, host.global_lag_grid_forcing_field, np.float64, factor=1e3,
+                     what="node forces")
+        assert_close(dev.body_flow_forces, host.body_flow_forces, np.float64, factor=1e3, what="body forces")
+        assert_close(dev.body_flow_torques, host.body_flow_torques, np.float64, factor=1e3, what="body torques")
+        assert_close(f_dev.get(), f_host.get(), real_t, factor=1.0, what="Eulerian forcing")
+    assert np.any(dev.body_flow_torques != 0)
+
+
 def test_ordered_spread_is_reproducible_and_follows_node_order(smi):
     """Many nodes in few cells: the node-ordered spread gives the same bits on every run and the oracle's
     serially accumulated values; the atomic spread agrees with both to rounding."""
