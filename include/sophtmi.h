@@ -79,6 +79,31 @@ int smi_set_exchange_callback(smi_ctx* ctx, smi_exchange_cb cb, void* user);
  * to smi_set_exchange_callback. */
 typedef int (*smi_alltoall_cb)(void* user, const void* send, void* recv, size_t bytes_per_peer);
 int smi_set_alltoall_callback(smi_ctx* ctx, smi_alltoall_cb cb);
+
+/* ---- pencil decomposition -------------------------------------------------------
+ * The reference's default for several ranks (utils/mpi_utils_3d.py:32-66: MPI.Compute_dims over z and y,
+ * x kept whole).  smi_ctx_set_pencil turns a context created as rank `rank_z * nranks_y + rank_y` of
+ * nranks_z * nranks_y ranks (the Cartesian order of Create_cart) into one block of a (nranks_z, nranks_y)
+ * grid: nz and ny of smi_ctx_create are then the local sizes of that block.  Halo exchange, ghost sum and
+ * the band logic of every operator follow the block's position; the Poisson solve runs on z-slabs
+ * (smi_pencil_to_slab / smi_slab_to_pencil move the right-hand side and the solution).
+ * Host-staged transports for tests: a pairwise exchange of device buffers with the two y neighbours
+ * (peer -1 = none) and an all-to-all of equal blocks inside a group of `count` consecutive ranks. */
+int smi_ctx_set_pencil(smi_ctx* ctx, int rank_z, int nranks_z, int rank_y, int nranks_y);
+typedef int (*smi_sendrecv_cb)(void* user, int peer_lo, int peer_hi, const void* send_lo, const void* send_hi,
+                               void* recv_lo, void* recv_hi, size_t bytes);
+int smi_set_sendrecv_callback(smi_ctx* ctx, smi_sendrecv_cb cb);
+typedef int (*smi_group_alltoall_cb)(void* user, const void* send, void* recv, size_t bytes_per_peer,
+                                     int first_rank, int count);
+int smi_set_group_alltoall_callback(smi_ctx* ctx, smi_group_alltoall_cb cb);
+/* MPIDomainDoublingCommunicator-style redistribution between the two decompositions of one grid:
+ * `pencil_field` (ncomp components, ghosted, on `pencil`) <-> `slab_field` (ghosted, on `slab`, a context of
+ * the same rank and rank count created with nz = global nz / nranks, ny = global ny).  Interiors only.
+ * work_a / work_b: two device buffers of ncomp * nz_pencil * ny_pencil * nx elements. */
+int smi_pencil_to_slab(smi_ctx* pencil, smi_ctx* slab, void* slab_field, const void* pencil_field, int ncomp,
+                       void* work_a, void* work_b);
+int smi_slab_to_pencil(smi_ctx* pencil, smi_ctx* slab, void* pencil_field, const void* slab_field, int ncomp,
+                       void* work_a, void* work_b);
 /* allreduce of n host doubles over the slab ranks through RCCL; op: 0 = sum, 1 = min,
  * 2 = max.  Replaces grid.allreduce (flow_simulators_mpi_3d.py:448, 465-467, 475). */
 int smi_allreduce_f64(smi_ctx* ctx, double* host_inout, int n, int op);

@@ -46,6 +46,93 @@ extern "C" int smi_allreduce_f64(smi_ctx* c, double* host_inout, int n, int op) 
 
 static inline ncclDataType_t nccl_type(const smi_ctx* c) { return c->dtype == SMI_F32 ? ncclFloat : ncclDouble; }
 
+// ---------------------------------------------------------------- y faces of a pencil
+// d rows of every plane (z ghost planes included) of every component <-> a contiguous buffer [comp][z][row][x]
+template <typename T, bool UNPACK, bool ADD>
+__global__ void __launch_bounds__(256) k_rows(T* __restrict__ field, T* __restrict__ buf, int pz, int px, int d, int y0,
+                                              long long plane, long long vol, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % px);
+  long long r = i / px;
+  const int row = (int)(r % d);
+  r /= d;
+  const int z = (int)(r % pz), comp = (int)(r / pz);
+  T* cell = field + comp * vol + z * plane + (long long)(y0 + row) * px + x;
+  if (!UNPACK)
+    buf[i] = *cell;
+  else if (ADD)
+    *cell += buf[i];
+  else
+    *cell = buf[i];
+}
+
+template <bool UNPACK, bool ADD>
+static int rows_copy(smi_ctx* c, void* field, void* buf, int ncomp, int d, int y0, hipStream_t stream) {
+  const long long n = (long long)ncomp * c->pz * d * c->px;
+  SMI_DISPATCH(c, {
+    k_rows<T, UNPACK, ADD><<<(int)((n + 255) / 256), 256, 0, stream>>>((T*)field, (T*)buf, c->pz, c->px, d, y0,
+                                                                      (long long)c->plane, (long long)c->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// Exchange with the two y neighbours (rank -/+ 1 inside the row of nranks_y ranks).
+// Halo (sum = false): my first / last d interior rows -> the neighbour's ghost rows next to its interior
+// (MPIGhostCommunicator3D, y faces).  Ghost sum (sum = true, d = g): my ghost rows are added to the neighbour's
+// edge interior rows (MPIGhostSumCommunicator3D.ghost_sum, the two y steps).
+int smi_y_face_exchange(smi_ctx* c, void* field, int ncomp, int d, bool sum, hipStream_t stream) {
+  if (c->nranks_y == 1) return 0;
+  SMI_REQUIRE(ncomp >= 1 && ncomp <= 3 && d >= 1 && d <= c->g, "y face exchange: bad argument");
+  const int g = c->g, py = c->py;
+  const bool lo = c->rank_y > 0, hi = c->rank_y < c->nranks_y - 1;
+  const size_t bytes = (size_t)ncomp * c->pz * d * c->px * smi_elem_size(c);
+  SMI_REQUIRE(bytes <= c->ybuf_cap, "y face exchange: staging buffer too small");
+  const int src_lo = sum ? 0 : g, src_hi = sum ? py - g : py - g - d;
+  const int dst_lo = sum ? g : g - d, dst_hi = sum ? py - 2 * g : py - g;
+  if (lo) SMI_CHECK((rows_copy<false, false>(c, field, c->ybuf[0], ncomp, d, src_lo, stream)));
+  if (hi) SMI_CHECK((rows_copy<false, false>(c, field, c->ybuf[1], ncomp, d, src_hi, stream)));
+  const int peer_lo = lo ? c->rank - 1 : -1, peer_hi = hi ? c->rank + 1 : -1;
+  if (c->sendrecv_cb) {
+    SMI_CHECK_HIP(hipStreamSynchronize(stream));
+    int rc = c->sendrecv_cb(c->exchange_user, peer_lo, peer_hi, c->ybuf[0], c->ybuf[1], c->ybuf[2], c->ybuf[3], bytes);
+    SMI_REQUIRE(rc == 0, "y face exchange callback failed (%d)", rc);
+  } else {
+    SMI_REQUIRE(c->comm_ready, "y face exchange across ranks needs smi_comm_init or a send-receive callback");
+    SMI_CHECK_NCCL(ncclGroupStart());
+    if (lo) {
+      SMI_CHECK_NCCL(ncclSend(c->ybuf[0], bytes, ncclChar, peer_lo, c->comm, stream));
+      SMI_CHECK_NCCL(ncclRecv(c->ybuf[2], bytes, ncclChar, peer_lo, c->comm, stream));
+    }
+    if (hi) {
+      SMI_CHECK_NCCL(ncclSend(c->ybuf[1], bytes, ncclChar, peer_hi, c->comm, stream));
+      SMI_CHECK_NCCL(ncclRecv(c->ybuf[3], bytes, ncclChar, peer_hi, c->comm, stream));
+    }
+    SMI_CHECK_NCCL(ncclGroupEnd());
+  }
+  if (sum) {
+    if (lo) SMI_CHECK((rows_copy<true, true>(c, field, c->ybuf[2], ncomp, d, dst_lo, stream)));
+    if (hi) SMI_CHECK((rows_copy<true, true>(c, field, c->ybuf[3], ncomp, d, dst_hi, stream)));
+  } else {
+    if (lo) SMI_CHECK((rows_copy<true, false>(c, field, c->ybuf[2], ncomp, d, dst_lo, stream)));
+    if (hi) SMI_CHECK((rows_copy<true, false>(c, field, c->ybuf[3], ncomp, d, dst_hi, stream)));
+  }
+  return 0;
+}
+
+extern "C" int smi_set_sendrecv_callback(smi_ctx* c, smi_sendrecv_cb cb) {
+  SMI_REQUIRE(c, "smi_set_sendrecv_callback: null context");
+  c->sendrecv_cb = cb;
+  return 0;
+}
+
+extern "C" int smi_set_group_alltoall_callback(smi_ctx* c, smi_group_alltoall_cb cb) {
+  SMI_REQUIRE(c, "smi_set_group_alltoall_callback: null context");
+  c->group_alltoall_cb = cb;
+  return 0;
+}
+
 // MPIGhostCommunicator3D z faces: my first / last d interior planes -> the neighbour's
 // high / low ghost planes next to its interior.  d = g (what the reference exchanges) unless the
 // fused step has lowered halo_depth to what its stencils read.  Two fields may travel in one
@@ -64,29 +151,34 @@ int smi_halo_exchange2_on(smi_ctx* c, void* field_a, int ncomp_a, void* field_b,
       if (!ncomps[f]) continue;
       int rc = c->exchange_cb(c->exchange_user, fields[f], ncomps[f], d == c->g ? 0 : 16 * d);
       SMI_REQUIRE(rc == 0, "halo exchange callback failed (%d)", rc);
+      SMI_CHECK(smi_y_face_exchange(c, fields[f], ncomps[f], d, false, stream));
     }
     return 0;
   }
   SMI_REQUIRE(c->comm_ready, "halo exchange across ranks needs smi_comm_init or an exchange callback");
   const size_t es = smi_elem_size(c);
   const size_t n = (size_t)d * c->plane;  // elements per face per component
-  SMI_CHECK_NCCL(ncclGroupStart());
+  const int zprev = c->rank - c->nranks_y, znext = c->rank + c->nranks_y;  // the z neighbours of a pencil
+  if (c->nranks_z > 1) {
+    SMI_CHECK_NCCL(ncclGroupStart());
+    for (int f = 0; f < 2; ++f)
+      for (int k = 0; k < ncomps[f]; ++k) {
+        char* p = (char*)fields[f] + (size_t)k * c->vol * es;
+        if (c->rank_z > 0) {
+          SMI_CHECK_NCCL(ncclSend(p + (size_t)c->g * c->plane * es, n, nccl_type(c), zprev, c->comm, stream));
+          SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->g - d) * c->plane * es, n, nccl_type(c), zprev, c->comm, stream));
+        }
+        if (c->rank_z < c->nranks_z - 1) {
+          SMI_CHECK_NCCL(ncclSend(p + (size_t)(c->pz - c->g - d) * c->plane * es, n, nccl_type(c), znext, c->comm,
+                                  stream));
+          SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), znext, c->comm, stream));
+        }
+      }
+    SMI_CHECK_NCCL(ncclGroupEnd());
+  }
+  // y faces after the z faces: their rows include the z ghost planes just received, which fills the edges
   for (int f = 0; f < 2; ++f)
-    for (int k = 0; k < ncomps[f]; ++k) {
-      char* p = (char*)fields[f] + (size_t)k * c->vol * es;
-      if (c->rank > 0) {
-        SMI_CHECK_NCCL(ncclSend(p + (size_t)c->g * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm, stream));
-        SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->g - d) * c->plane * es, n, nccl_type(c), c->rank - 1, c->comm,
-                                stream));
-      }
-      if (c->rank < c->nranks - 1) {
-        SMI_CHECK_NCCL(ncclSend(p + (size_t)(c->pz - c->g - d) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
-                                stream));
-        SMI_CHECK_NCCL(ncclRecv(p + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
-                                stream));
-      }
-    }
-  SMI_CHECK_NCCL(ncclGroupEnd());
+    if (ncomps[f]) SMI_CHECK(smi_y_face_exchange(c, fields[f], ncomps[f], d, false, stream));
   return 0;
 }
 
@@ -226,31 +318,33 @@ extern "C" int smi_clear_ghost_cells(smi_ctx* c, void* field, int ncomp) {
   return 0;
 }
 
-// MPIGhostSumCommunicator3D.ghost_sum for z-slabs: my high ghost planes are added to the
-// next rank's first interior planes, my low ghost planes to the previous rank's last
-// interior planes (y and x neighbours are PROC_NULL), then all ghosts are zeroed.
+// MPIGhostSumCommunicator3D.ghost_sum: my high ghost planes are added to the next z rank's first interior planes,
+// my low ghost planes to the previous z rank's last interior planes; then the same with the ghost rows and the y
+// neighbours of a pencil (whole faces travel, so what arrived in a ghost row from a z neighbour moves on to the
+// diagonal rank: the cascade of the reference's z -> y -> x sequence); then all ghosts are zeroed.
 extern "C" int smi_ghost_sum(smi_ctx* c, void* field, int ncomp) {
   SMI_REQUIRE(c && field && ncomp >= 1 && ncomp <= 3, "smi_ghost_sum: bad argument");
   if (c->nranks > 1 && c->exchange_cb) {
     int rc = c->exchange_cb(c->exchange_user, field, ncomp, 1);
     SMI_REQUIRE(rc == 0, "ghost sum callback failed (%d)", rc);
-  } else if (c->nranks > 1) {
+  } else if (c->nranks_z > 1) {
     SMI_REQUIRE(c->comm_ready, "smi_ghost_sum across ranks needs smi_comm_init or an exchange callback");
     const size_t es = smi_elem_size(c);
     const size_t n = (size_t)c->g * c->plane;
     SMI_REQUIRE((size_t)ncomp * n * es <= c->halo_cap, "smi_ghost_sum: staging buffer too small");
     char* base = (char*)field;
     SMI_CHECK_NCCL(ncclGroupStart());
+    const int zprev = c->rank - c->nranks_y, znext = c->rank + c->nranks_y;
     for (int k = 0; k < ncomp; ++k) {
       char* f = base + (size_t)k * c->vol * es;
-      if (c->rank > 0) {
-        SMI_CHECK_NCCL(ncclSend(f, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
-        SMI_CHECK_NCCL(ncclRecv((char*)c->halo_recv[0] + k * n * es, n, nccl_type(c), c->rank - 1, c->comm, c->stream));
+      if (c->rank_z > 0) {
+        SMI_CHECK_NCCL(ncclSend(f, n, nccl_type(c), zprev, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv((char*)c->halo_recv[0] + k * n * es, n, nccl_type(c), zprev, c->comm, c->stream));
       }
-      if (c->rank < c->nranks - 1) {
-        SMI_CHECK_NCCL(ncclSend(f + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), c->rank + 1, c->comm,
+      if (c->rank_z < c->nranks_z - 1) {
+        SMI_CHECK_NCCL(ncclSend(f + (size_t)(c->pz - c->g) * c->plane * es, n, nccl_type(c), znext, c->comm,
                                 c->stream));
-        SMI_CHECK_NCCL(ncclRecv((char*)c->halo_recv[1] + k * n * es, n, nccl_type(c), c->rank + 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv((char*)c->halo_recv[1] + k * n * es, n, nccl_type(c), znext, c->comm, c->stream));
       }
     }
     SMI_CHECK_NCCL(ncclGroupEnd());
@@ -258,15 +352,149 @@ extern "C" int smi_ghost_sum(smi_ctx* c, void* field, int ncomp) {
     for (int k = 0; k < ncomp; ++k) {
       char* f = base + (size_t)k * c->vol * es;
       SMI_DISPATCH(c, {
-        if (c->rank > 0)
+        if (c->rank_z > 0)
           k_add<T><<<blocks, 256, 0, c->stream>>>((T*)(f + (size_t)c->g * c->plane * es),
                                                  (const T*)((char*)c->halo_recv[0] + k * n * es), n);
-        if (c->rank < c->nranks - 1)
+        if (c->rank_z < c->nranks_z - 1)
           k_add<T><<<blocks, 256, 0, c->stream>>>((T*)(f + (size_t)(c->pz - 2 * c->g) * c->plane * es),
                                                  (const T*)((char*)c->halo_recv[1] + k * n * es), n);
       });
       SMI_LAUNCH_CHECK();
     }
   }
+  SMI_CHECK(smi_y_face_exchange(c, field, ncomp, c->g, true, c->stream));
   return smi_clear_ghost_cells(c, field, ncomp);
+}
+
+// ---------------------------------------------------------------- pencil <-> slab redistribution
+// Rank (rz, ry) of a pencil grid holds planes [rz nzp, (rz + 1) nzp) and rows [ry nyp, (ry + 1) nyp); as rank
+// s = rz Py + ry of the slab decomposition of the same grid it holds planes [s nzs, (s + 1) nzs), nzs = nzp / Py,
+// and every row.  The planes of a pencil are therefore the slabs of the Py ranks of its own row of the rank grid:
+// one all-to-all of equal blocks inside that row moves a field between the two.
+// Block for peer j (pencil -> slab): [comp][nzs planes j nzs ..][nyp][nx], interior cells only.
+template <typename T, bool TO_WORK>
+__global__ void __launch_bounds__(256) k_pencil_blocks(T* __restrict__ work, T* __restrict__ pencil, int ncomp, int nzs,
+                                                       int nyp, int nx, int g, int px, long long plane, long long vol,
+                                                       long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % nx);
+  long long r = i / nx;
+  const int y = (int)(r % nyp);
+  r /= nyp;
+  const int z = (int)(r % nzs);
+  r /= nzs;
+  const int comp = (int)(r % ncomp), j = (int)(r / ncomp);
+  T* cell = pencil + comp * vol + (long long)(g + j * nzs + z) * plane + (long long)(g + y) * px + g + x;
+  if (TO_WORK)
+    work[i] = *cell;
+  else
+    *cell = work[i];
+}
+// Block from peer j (in the slab): [comp][nzs][nyp rows j nyp ..][nx]
+template <typename T, bool TO_WORK>
+__global__ void __launch_bounds__(256) k_slab_blocks(T* __restrict__ work, T* __restrict__ slab, int ncomp, int nzs,
+                                                     int nyp, int nx, int g, int px, long long plane, long long vol,
+                                                     long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % nx);
+  long long r = i / nx;
+  const int y = (int)(r % nyp);
+  r /= nyp;
+  const int z = (int)(r % nzs);
+  r /= nzs;
+  const int comp = (int)(r % ncomp), j = (int)(r / ncomp);
+  T* cell = slab + comp * vol + (long long)(g + z) * plane + (long long)(g + j * nyp + y) * px + g + x;
+  if (TO_WORK)
+    work[i] = *cell;
+  else
+    *cell = work[i];
+}
+
+static int group_alltoall(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer, int first, int count) {
+  if (count == 1) {
+    SMI_CHECK_HIP(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+  }
+  if (c->group_alltoall_cb) {
+    SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+    int rc = c->group_alltoall_cb(c->exchange_user, send, recv, bytes_per_peer, first, count);
+    SMI_REQUIRE(rc == 0, "group all-to-all callback failed (%d)", rc);
+    return 0;
+  }
+  SMI_REQUIRE(c->comm_ready, "redistribution across ranks needs smi_comm_init or a transport callback");
+  const int me = c->rank - first;
+  SMI_CHECK_HIP(hipMemcpyAsync((char*)recv + (size_t)me * bytes_per_peer, (const char*)send + (size_t)me * bytes_per_peer,
+                               bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
+  SMI_CHECK_NCCL(ncclGroupStart());
+  for (int j = 0; j < count; ++j) {
+    if (j == me) continue;
+    SMI_CHECK_NCCL(ncclSend((const char*)send + (size_t)j * bytes_per_peer, bytes_per_peer, ncclChar, first + j, c->comm,
+                            c->stream));
+    SMI_CHECK_NCCL(ncclRecv((char*)recv + (size_t)j * bytes_per_peer, bytes_per_peer, ncclChar, first + j, c->comm,
+                            c->stream));
+  }
+  SMI_CHECK_NCCL(ncclGroupEnd());
+  return 0;
+}
+
+static int redistribution_shapes(const smi_ctx* p, const smi_ctx* s, int ncomp, const char* who) {
+  SMI_REQUIRE(p && s && ncomp >= 1 && ncomp <= 3, "%s: bad argument", who);
+  SMI_REQUIRE(p->dtype == s->dtype && p->g == s->g && p->nx == s->nx && p->rank == s->rank && p->nranks == s->nranks &&
+                  s->nranks_y == 1,
+              "%s: the two contexts do not describe the same rank, precision and ghost size", who);
+  SMI_REQUIRE(p->nz % p->nranks_y == 0 && s->nz == p->nz / p->nranks_y && s->ny == p->ny * p->nranks_y,
+              "%s: a pencil of %d x %d does not split into slabs of %d x %d over %d ranks", who, p->nz, p->ny, s->nz,
+              s->ny, p->nranks_y);
+  return 0;
+}
+
+extern "C" int smi_pencil_to_slab(smi_ctx* p, smi_ctx* sl, void* slab_field, const void* pencil_field, int ncomp,
+                                  void* work_a, void* work_b) {
+  SMI_CHECK(redistribution_shapes(p, sl, ncomp, "smi_pencil_to_slab"));
+  SMI_REQUIRE(slab_field && pencil_field && work_a && work_b, "smi_pencil_to_slab: null array");
+  smi_ctx* c = p;
+  const int Py = p->nranks_y, nzs = sl->nz, nyp = p->ny, nx = p->nx;
+  const long long n = (long long)Py * ncomp * nzs * nyp * nx;
+  const size_t per_peer = (size_t)ncomp * nzs * nyp * nx * smi_elem_size(p);
+  SMI_DISPATCH(c, {
+    k_pencil_blocks<T, true><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_a, (T*)pencil_field, ncomp, nzs, nyp,
+                                                                            nx, p->g, p->px, (long long)p->plane,
+                                                                            (long long)p->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK(group_alltoall(p, work_a, work_b, per_peer, p->rank_z * Py, Py));
+  // the unpack runs on the pencil context's stream too: the caller orders the slab context's work behind it
+  SMI_DISPATCH(c, {
+    k_slab_blocks<T, false><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_b, (T*)slab_field, ncomp, nzs, nyp, nx,
+                                                                           sl->g, sl->px, (long long)sl->plane,
+                                                                           (long long)sl->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi_slab_to_pencil(smi_ctx* p, smi_ctx* sl, void* pencil_field, const void* slab_field, int ncomp,
+                                  void* work_a, void* work_b) {
+  SMI_CHECK(redistribution_shapes(p, sl, ncomp, "smi_slab_to_pencil"));
+  SMI_REQUIRE(slab_field && pencil_field && work_a && work_b, "smi_slab_to_pencil: null array");
+  smi_ctx* c = p;
+  const int Py = p->nranks_y, nzs = sl->nz, nyp = p->ny, nx = p->nx;
+  const long long n = (long long)Py * ncomp * nzs * nyp * nx;
+  const size_t per_peer = (size_t)ncomp * nzs * nyp * nx * smi_elem_size(p);
+  SMI_DISPATCH(c, {
+    k_slab_blocks<T, true><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_a, (T*)slab_field, ncomp, nzs, nyp, nx,
+                                                                          sl->g, sl->px, (long long)sl->plane,
+                                                                          (long long)sl->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK(group_alltoall(p, work_a, work_b, per_peer, p->rank_z * Py, Py));
+  SMI_DISPATCH(c, {
+    k_pencil_blocks<T, false><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_b, (T*)pencil_field, ncomp, nzs, nyp,
+                                                                             nx, p->g, p->px, (long long)p->plane,
+                                                                             (long long)p->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
 }

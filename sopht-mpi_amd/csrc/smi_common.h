@@ -21,6 +21,18 @@ struct smi_ctx {
   size_t vol;          // pz * py * px
   int rank, nranks;
   int phys_zlo, phys_zhi;  // is the low / high z face a physical boundary
+  // Pencil decomposition (smi_ctx_set_pencil): the ranks form a (nranks_z, nranks_y) grid, rank = rank_z * nranks_y +
+  // rank_y (the Cartesian order of the reference's MPI.Compute_dims / Create_cart topology); x is never divided.
+  // z-slabs are nranks_y = 1.
+  int rank_z, nranks_z, rank_y, nranks_y;
+  int phys_ylo, phys_yhi;
+  // y faces are strided in memory: they are packed into / unpacked from these device buffers
+  // ([0] to the previous y rank, [1] to the next, [2] from the previous, [3] from the next; 3 components of g rows
+  // of every plane each), allocated by smi_ctx_set_pencil
+  void* ybuf[4];
+  size_t ybuf_cap;
+  smi_sendrecv_cb sendrecv_cb;
+  smi_group_alltoall_cb group_alltoall_cb;
   hipStream_t stream;
   hipStream_t comm_stream;
   hipEvent_t ev_a, ev_b;
@@ -124,6 +136,7 @@ int smi_halo_exchange_impl(smi_ctx* ctx, void* field, int ncomp);
 int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* field_b, int ncomp_b);
 // the same exchange queued on `stream` (RCCL transport only: the host-staged callback works on the context's stream)
 int smi_halo_exchange2_on(smi_ctx* ctx, void* field_a, int ncomp_a, void* field_b, int ncomp_b, hipStream_t stream);
+int smi_y_face_exchange(smi_ctx* ctx, void* field, int ncomp, int depth, bool sum, hipStream_t stream);
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);

@@ -64,6 +64,11 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   c->nranks = nranks;
   c->phys_zlo = rank == 0;
   c->phys_zhi = rank == nranks - 1;
+  c->rank_z = rank;
+  c->nranks_z = nranks;
+  c->rank_y = 0;
+  c->nranks_y = 1;
+  c->phys_ylo = c->phys_yhi = 1;
   // staging for the ghost sum (and the host-staged plane upload): 3 components of g planes
   c->halo_cap = (size_t)3 * ghost * c->plane * smi_elem_size(c);
   const int rc = ctx_allocate(c);
@@ -75,6 +80,31 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   return 0;
 }
 
+extern "C" int smi_ctx_set_pencil(smi_ctx* c, int rank_z, int nranks_z, int rank_y, int nranks_y) {
+  SMI_REQUIRE(c, "smi_ctx_set_pencil: null context");
+  SMI_REQUIRE(nranks_z >= 1 && nranks_y >= 1 && nranks_z * nranks_y == c->nranks,
+              "smi_ctx_set_pencil: a %d x %d rank grid does not hold the %d ranks of this context", nranks_z, nranks_y,
+              c->nranks);
+  SMI_REQUIRE(rank_z >= 0 && rank_z < nranks_z && rank_y >= 0 && rank_y < nranks_y &&
+                  rank_z * nranks_y + rank_y == c->rank,
+              "smi_ctx_set_pencil: position (%d, %d) is not rank %d of a %d x %d grid", rank_z, rank_y, c->rank,
+              nranks_z, nranks_y);
+  c->rank_z = rank_z;
+  c->nranks_z = nranks_z;
+  c->rank_y = rank_y;
+  c->nranks_y = nranks_y;
+  c->phys_zlo = rank_z == 0;
+  c->phys_zhi = rank_z == nranks_z - 1;
+  c->phys_ylo = rank_y == 0;
+  c->phys_yhi = rank_y == nranks_y - 1;
+  if (nranks_y > 1 && !c->ybuf[0]) {
+    SMI_CHECK_HIP(hipSetDevice(c->device));
+    c->ybuf_cap = (size_t)3 * c->pz * c->g * c->px * smi_elem_size(c);
+    for (int i = 0; i < 4; ++i) SMI_CHECK_HIP(hipMalloc(&c->ybuf[i], c->ybuf_cap));
+  }
+  return 0;
+}
+
 extern "C" int smi_ctx_destroy(smi_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->device);
@@ -83,6 +113,9 @@ extern "C" int smi_ctx_destroy(smi_ctx* c) {
   if (c->comm_ready) ncclCommDestroy(c->comm);
   for (int i = 0; i < 2; ++i) {
     if (c->halo_recv[i]) hipFree(c->halo_recv[i]);
+  }
+  for (int i = 0; i < 4; ++i) {
+    if (c->ybuf[i]) hipFree(c->ybuf[i]);
   }
   delete c->prof;
   if (c->red_partials) hipFree(c->red_partials);

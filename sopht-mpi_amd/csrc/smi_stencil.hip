@@ -25,6 +25,7 @@ struct Geo {
   int pz, py, px, g;
   long long plane, vol;
   int zlo_c, zhi_c;  // inclusive z range of the zero-banded compute set D
+  int ylo_c, yhi_c;  // the same in y (differs from [g + 1, py - g - 2] only on the inner faces of a pencil)
   // z range over which the one-pass advection + diffusion kernel forms the advected vorticity on the core cells:
   // the planes the vorticity update writes there, [g, pz - g - 1], plus the ghost plane next to a neighbouring
   // rank (what that rank computes for its own edge plane, needed by the diffusion stencil of this rank's edge)
@@ -43,6 +44,8 @@ Geo make_geo(const smi_ctx* c) {
   // at a rank boundary the first / last interior plane is computed from exchanged ghosts.
   G.zlo_c = c->g + (c->phys_zlo ? 1 : 0);
   G.zhi_c = c->pz - c->g - 1 - (c->phys_zhi ? 1 : 0);
+  G.ylo_c = c->g + (c->phys_ylo ? 1 : 0);
+  G.yhi_c = c->py - c->g - 1 - (c->phys_yhi ? 1 : 0);
   G.za_lo = c->g - (c->phys_zlo ? 0 : 1);
   G.za_hi = c->pz - c->g - 1 + (c->phys_zhi ? 0 : 1);
   return G;
@@ -144,6 +147,8 @@ __device__ __forceinline__ bool lane_pos(const Geo& G, const Blk& B, long long& 
 }
 
 __device__ __forceinline__ bool in_core(int a, int p, int g) { return a >= g + 1 && a <= p - g - 2; }
+// rows of the zero-banded compute set D (in_core(y) unless a y face of this rank borders another rank)
+__device__ __forceinline__ bool in_core_y(const Geo& G, int y) { return y >= G.ylo_c && y <= G.yhi_c; }
 __device__ __forceinline__ bool on_face(int a, int p, int g) { return a == g || a == p - g - 1; }
 __device__ __forceinline__ bool in_ext(int a, int p) { return a >= 1 && a <= p - 2; }
 
@@ -161,7 +166,7 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
   flux += (long long)B.z * G.vol + q;
   f += (long long)B.z * G.vol + q;
   bool core[V], any = false;
-  bool ycore = in_core(y, G.py, G.g);
+  bool ycore = in_core_y(G, y);
 #pragma unroll
   for (int e = 0; e < V; ++e) {
     core[e] = ycore && in_core(x0 + e, G.px, G.g);
@@ -227,7 +232,9 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
   T* oy = out + G.vol + q;
   T* oz = out + 2 * G.vol + q;
   bool mA[V], mB[V], any = false;
-  const bool yc = in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
+  // MODE 0 masks with the zero-banded set D, whose y range depends on the rank's position; the update set U of
+  // MODE 1 is the same on every rank
+  const bool yc = MODE == 0 ? in_core_y(G, y) : in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
 #pragma unroll
   for (int e = 0; e < V; ++e) {
     bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
@@ -1126,7 +1133,7 @@ __global__ void __launch_bounds__(kBlock) k_divergence(T* __restrict__ div, cons
   int z = (int)(i / G.plane);
   long long r = i - (long long)z * G.plane;
   int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
-  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core(y, G.py, G.g) && in_core(x, G.px, G.g);
+  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core_y(G, y) && in_core(x, G.px, G.g);
   T v = T(0);
   if (ok) {
     const T* fx = f + i;
@@ -1147,7 +1154,7 @@ __global__ void __launch_bounds__(kBlock) k_filter_pass(T* __restrict__ flux, co
   int z = (int)(i / G.plane);
   long long r = i - (long long)z * G.plane;
   int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
-  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core(y, G.py, G.g) && in_core(x, G.px, G.g);
+  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core_y(G, y) && in_core(x, G.px, G.g);
   T v = T(0);
   if (ok) {
     const long long d = AXIS == 0 ? 1 : (AXIS == 1 ? (long long)G.px : G.plane);
@@ -1229,13 +1236,15 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
 
 // zero the outer (g + width) layers next to physical faces (zero_bands of the wrappers)
 template <typename T>
-__global__ void __launch_bounds__(kBlock) k_zero_bands(T* __restrict__ f, Geo G, int w, int zlo, int zhi) {
+__global__ void __launch_bounds__(kBlock) k_zero_bands(T* __restrict__ f, Geo G, int w, int zlo, int zhi, int ylo,
+                                                      int yhi) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.vol) return;
   int z = (int)(i / G.plane);
   long long r = i - (long long)z * G.plane;
   int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
-  bool band = x < w || x >= G.px - w || y < w || y >= G.py - w || (zlo && z < w) || (zhi && z >= G.pz - w);
+  bool band = x < w || x >= G.px - w || (ylo && y < w) || (yhi && y >= G.py - w) || (zlo && z < w) ||
+              (zhi && z >= G.pz - w);
   if (band) f[i] = T(0);
 }
 
@@ -1285,7 +1294,8 @@ __global__ void __launch_bounds__(kBlock) k_penalise(T* __restrict__ f, Geo G, i
 
 template <typename T>
 bool vec_ok(const smi_ctx* c, const void* a, const void* b) {
-  return c->px % 4 == 0 && ((uintptr_t)a % (4 * sizeof(T))) == 0 && ((uintptr_t)b % (4 * sizeof(T))) == 0 &&
+  // the LDS-tiled kernels take their y limits from the array shape: a pencil (inner y faces) runs the plain kernels
+  return c->nranks_y == 1 && c->px % 4 == 0 && ((uintptr_t)a % (4 * sizeof(T))) == 0 && ((uintptr_t)b % (4 * sizeof(T))) == 0 &&
          (c->vol % 4) == 0;
 }
 
@@ -1689,8 +1699,9 @@ extern "C" int smi_penalise_boundary(smi_ctx* c, void* field, int ncomp, int wid
   SMI_DISPATCH(c, {
     k_penalise<T, 0><<<blocks_for((long long)G.pz * G.py * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
                                                                                          fac, 1, 1);
-    k_penalise<T, 1><<<blocks_for((long long)G.pz * G.px * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
-                                                                                         fac, 1, 1);
+    if (c->phys_ylo || c->phys_yhi)
+      k_penalise<T, 1><<<blocks_for((long long)G.pz * G.px * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
+                                                                                           fac, c->phys_ylo, c->phys_yhi);
     if (c->phys_zlo || c->phys_zhi)
       k_penalise<T, 2><<<blocks_for(G.plane * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w, fac,
                                                                              c->phys_zlo, c->phys_zhi);
@@ -1754,7 +1765,9 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
   G.g = c->g + w - 1;
   G.zlo_c = c->g + (c->phys_zlo ? w : 0);
   G.zhi_c = c->pz - c->g - 1 - (c->phys_zhi ? w : 0);
-  if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1 && w == 1) {
+  G.ylo_c = c->g + (c->phys_ylo ? w : 0);
+  G.yhi_c = c->py - c->g - 1 - (c->phys_yhi ? w : 0);
+  if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1 && w == 1 && c->nranks_y == 1) {
     // one fused pass into the scratch field, then back (the scratch fields hold one component)
     const size_t stride = c->vol * smi_elem_size(c);
     for (int k = 0; k < ncomp; ++k) {
@@ -1776,7 +1789,8 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
       if (filter_type == SMI_FILTER_MULTIPLICATIVE) {
         if (order == 0) {
           // degenerate: field -= (stale flux buffer with its physical bands cleared)
-          k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi);
+          k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi,
+                                                                       c->phys_ylo, c->phys_yhi);
           SMI_LAUNCH_CHECK();
           SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
           continue;
@@ -1793,7 +1807,8 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
       } else {
         for (int axis = 0; axis < 3; ++axis) {
           if (order == 0) {
-            k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi);
+            k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi,
+                                                                       c->phys_ylo, c->phys_yhi);
             SMI_LAUNCH_CHECK();
             SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
             continue;

@@ -34,6 +34,9 @@ _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+SENDRECV_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_size_t)
+GROUP_ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
 
 # name -> argtypes; every function returns int status unless listed in _SPECIAL
 SIGNATURES = {
@@ -45,6 +48,11 @@ SIGNATURES = {
     "smi_comm_init": [_p, _p],
     "smi_set_exchange_callback": [_p, EXCHANGE_CB, _p],
     "smi_set_alltoall_callback": [_p, ALLTOALL_CB],
+    "smi_ctx_set_pencil": [_p, _i, _i, _i, _i],
+    "smi_set_sendrecv_callback": [_p, SENDRECV_CB],
+    "smi_set_group_alltoall_callback": [_p, GROUP_ALLTOALL_CB],
+    "smi_pencil_to_slab": [_p, _p, _p, _p, _i, _p, _p],
+    "smi_slab_to_pencil": [_p, _p, _p, _p, _i, _p, _p],
     "smi_allreduce_f64": [_p, _dp, _i, _i],
     "smi_malloc": [_p, _sz, _pp],
     "smi_free": [_p, _p],

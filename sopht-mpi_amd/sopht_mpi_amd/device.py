@@ -34,9 +34,11 @@ def local_device():
 
 
 class DeviceContext:
-    """One GPU holding one z-slab: grid geometry + HIP stream + (optionally) RCCL comm."""
+    """One GPU holding one block of the grid (a z-slab, or a pencil of a (ranks along z, ranks along y) grid):
+    geometry + HIP stream + (optionally) RCCL comm."""
 
-    def __init__(self, local_grid_size, ghost_size, real_t, rank=0, nranks=1, device=None, world=None):
+    def __init__(self, local_grid_size, ghost_size, real_t, rank=0, nranks=1, device=None, world=None,
+                 rank_grid=None):
         self.real_t = np.dtype(real_t).type
         self.local_grid_size = tuple(int(n) for n in local_grid_size)
         self.ghost_size = int(ghost_size)
@@ -48,6 +50,10 @@ class DeviceContext:
         call("smi_ctx_create", C.byref(h), self.device, _dtype_code(real_t), nz, ny, nx, self.ghost_size,
              self.rank, self.nranks)
         self.handle = h
+        self.rank_grid = (self.nranks, 1) if rank_grid is None else (int(rank_grid[0]), int(rank_grid[1]))
+        self.rank_z, self.rank_y = divmod(self.rank, self.rank_grid[1])
+        if self.rank_grid[1] > 1:
+            call("smi_ctx_set_pencil", h, self.rank_z, self.rank_grid[0], self.rank_y, self.rank_grid[1])
         self.padded_shape = tuple(n + 2 * self.ghost_size for n in self.local_grid_size)
         self.transport = "none" if nranks == 1 else None
         self._cb = None
@@ -75,8 +81,9 @@ class DeviceContext:
         """Host-staged plane transport through the world's point-to-point (ranks sharing a GPU)."""
         g, pz = self.ghost_size, self.padded_shape[0]
         plane = self.padded_shape[1] * self.padded_shape[2]
-        prev = self.rank - 1 if self.rank > 0 else None
-        nxt = self.rank + 1 if self.rank < self.nranks - 1 else None
+        ranks_y = self.rank_grid[1]
+        prev = self.rank - ranks_y if self.rank_z > 0 else None                    # the z neighbours
+        nxt = self.rank + ranks_y if self.rank_z < self.rank_grid[0] - 1 else None
         dt = np.dtype(self.real_t)
 
         def exchange(_user, field, ncomp, kind):
@@ -130,10 +137,55 @@ class DeviceContext:
                 self._cb_error = exc
                 return 1
 
+        def sendrecv(_user, peer_lo, peer_hi, send_lo, send_hi, recv_lo, recv_hi, nbytes):
+            """Device buffers <-> the two y neighbours (peer -1: none)."""
+            try:
+                sends, recvs = {}, {}
+                for peer, src in ((peer_lo, send_lo), (peer_hi, send_hi)):
+                    if peer >= 0:
+                        sends[peer] = np.empty(nbytes, dtype=np.uint8)
+                        call("smi_memcpy_d2h", self.handle, sends[peer].ctypes.data, src, nbytes)
+                        recvs[peer] = np.empty(nbytes, dtype=np.uint8)
+                self.world.sendrecv(sends, recvs)
+                for peer, dst in ((peer_lo, recv_lo), (peer_hi, recv_hi)):
+                    if peer >= 0:
+                        call("smi_memcpy_h2d", self.handle, dst, recvs[peer].ctypes.data, nbytes)
+                return 0
+            except Exception as exc:
+                import traceback
+
+                traceback.print_exc()
+                self._cb_error = exc
+                return 1
+
+        def group_alltoall(_user, send, recv, nbytes, first, count):
+            """Equal blocks among the ranks first .. first + count - 1 (this rank among them)."""
+            try:
+                me = self.rank - first
+                host = np.empty(count * nbytes, dtype=np.uint8)
+                call("smi_memcpy_d2h", self.handle, host.ctypes.data, send, count * nbytes)
+                out = np.empty(count * nbytes, dtype=np.uint8)
+                out[me * nbytes : (me + 1) * nbytes] = host[me * nbytes : (me + 1) * nbytes]
+                sends = {first + j: host[j * nbytes : (j + 1) * nbytes] for j in range(count) if j != me}
+                recvs = {first + j: out[j * nbytes : (j + 1) * nbytes] for j in range(count) if j != me}
+                self.world.sendrecv(sends, recvs)
+                call("smi_memcpy_h2d", self.handle, recv, out.ctypes.data, count * nbytes)
+                return 0
+            except Exception as exc:
+                import traceback
+
+                traceback.print_exc()
+                self._cb_error = exc
+                return 1
+
         self._cb = _lib.EXCHANGE_CB(exchange)
         self._cb2 = _lib.ALLTOALL_CB(alltoall)
+        self._cb3 = _lib.SENDRECV_CB(sendrecv)
+        self._cb4 = _lib.GROUP_ALLTOALL_CB(group_alltoall)
         call("smi_set_exchange_callback", self.handle, self._cb, None)
         call("smi_set_alltoall_callback", self.handle, self._cb2)
+        call("smi_set_sendrecv_callback", self.handle, self._cb3)
+        call("smi_set_group_alltoall_callback", self.handle, self._cb4)
         self.transport = "host"
 
     def allreduce(self, value, op):

@@ -263,6 +263,17 @@ class UnboundedPoissonSolverMPI3D:
         self.real_t = real_t
         self.dx = real_t(x_range / grid_size_x)
         self.ctx = mpi_construct.device_context(ghost_size)
+        # The transforms run on z-slabs.  A pencil decomposition moves the right-hand side to the slab decomposition
+        # of the same grid and the solution back (one all-to-all of real data inside each row of the rank grid,
+        # smi_pencil_to_slab / smi_slab_to_pencil), the way the reference's solver moves its fields between the
+        # grid's and the doubled domain's decomposition (UnboundedPoissonSolverMPI3D.py:190-382).
+        self.pencil_ctx = None
+        if mpi_construct.size > 1 and mpi_construct.grid_topology[1] > 1:
+            self.pencil_ctx = self.ctx
+            self.ctx = mpi_construct.slab_context(ghost_size)
+            block = int(np.prod(self.pencil_ctx.local_grid_size))
+            self._slab_rhs, self._slab_sol = self.ctx.field(3), self.ctx.field(3)
+            self._work = (self.pencil_ctx.zeros((3 * block,)), self.pencil_ctx.zeros((3 * block,)))
         names = {"rocfft": _lib.SMI_POISSON_ROCFFT, "pruned": _lib.SMI_POISSON_PRUNED}
         if backend is None:
             backend = "pruned" if self.backend_supports("pruned", grid_size_z, grid_size_y, grid_size_x,
@@ -283,11 +294,25 @@ class UnboundedPoissonSolverMPI3D:
 
     def solve(self, solution_field, rhs_field):
         """-del^2(solution_field) = rhs_field, unbounded domain (:133-167)."""
+        if self.pencil_ctx is not None:
+            return self._solve_through_slabs("smi_poisson_solve", solution_field, rhs_field, 1)
         call("smi_poisson_solve", self.handle, as_ptr(solution_field), as_ptr(rhs_field))
 
     def vector_field_solve(self, solution_vector_field, rhs_vector_field):
         """:169-187."""
+        if self.pencil_ctx is not None:
+            return self._solve_through_slabs("smi_poisson_vector_solve", solution_vector_field, rhs_vector_field, 3)
         call("smi_poisson_vector_solve", self.handle, as_ptr(solution_vector_field), as_ptr(rhs_vector_field))
+
+    def _solve_through_slabs(self, entry, solution, rhs, ncomp):
+        pencil, slab = self.pencil_ctx, self.ctx
+        work_a, work_b = (as_ptr(w) for w in self._work)
+        call("smi_pencil_to_slab", pencil.handle, slab.handle, as_ptr(self._slab_rhs), as_ptr(rhs), ncomp, work_a, work_b)
+        pencil.sync()   # the two contexts have their own streams
+        call(entry, self.handle, as_ptr(self._slab_sol), as_ptr(self._slab_rhs))
+        slab.sync()
+        call("smi_slab_to_pencil", pencil.handle, slab.handle, as_ptr(solution), as_ptr(self._slab_sol), ncomp, work_a,
+             work_b)
 
     def __del__(self):
         try:

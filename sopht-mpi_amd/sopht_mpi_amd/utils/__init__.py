@@ -1,6 +1,6 @@
 """Distributed plumbing with the reference's names (sopht_mpi/utils/mpi_utils_3d.py).
 
-``MPIConstruct3D`` describes the z-slab decomposition (one process per GPU),
+``MPIConstruct3D`` describes the decomposition (z-slabs, or pencils over z and y; one process per GPU),
 ``MPIGhostCommunicator3D`` the halo exchange, ``MPIFieldCommunicator3D`` host <-> device
 scatter / gather of global arrays, ``MPILagrangianFieldCommunicator3D`` the ownership
 map of Lagrangian nodes.
@@ -34,7 +34,8 @@ class _Grid:
 
     def __init__(self, construct):
         self._c = construct
-        self.coords = np.array([construct.rank, 0, 0])
+        self.coords = np.array([construct.rank // construct.grid_topology[1],
+                                construct.rank % construct.grid_topology[1], 0])
 
     def Get_size(self):
         return self._c.size
@@ -49,15 +50,46 @@ class _Grid:
         return self._c.world.bcast_object(obj, root)
 
     def Get_cart_rank(self, coords):
-        return int(coords[0])
+        return int(coords[0]) * int(self._c.grid_topology[1]) + int(coords[1])
+
+
+def compute_dims(nranks, dims):
+    """MPI.Compute_dims (MPI_Dims_create) for three dimensions: entries of ``dims`` that are 0 are filled with a
+    balanced factorisation of ``nranks`` in non-increasing order, the others are kept (utils/mpi_utils_3d.py:46-48)."""
+    dims = [int(d) for d in dims]
+    fixed = int(np.prod([d for d in dims if d > 0])) if any(d > 0 for d in dims) else 1
+    free = [i for i, d in enumerate(dims) if d == 0]
+    if nranks % fixed:
+        raise RuntimeError(f"{nranks} ranks cannot fill a topology with fixed dimensions {dims}")
+    rest = nranks // fixed
+    if not free:
+        if rest != 1:
+            raise RuntimeError(f"{nranks} ranks do not fit the fixed topology {dims}")
+        return dims
+    # balanced: strip prime factors, largest first, onto the currently smallest entry; then sort descending
+    parts = [1] * len(free)
+    n, f, factors = rest, 2, []
+    while n > 1:
+        while n % f == 0:
+            factors.append(f)
+            n //= f
+        f += 1
+    for f in sorted(factors, reverse=True):
+        parts[int(np.argmin(parts))] *= f
+    for i, v in zip(free, sorted(parts, reverse=True)):
+        dims[i] = v
+    return dims
 
 
 class MPIConstruct3D:
-    """utils/mpi_utils_3d.py:7-83 restricted to z-slabs.
+    """utils/mpi_utils_3d.py:7-83.
 
-    ``rank_distribution`` follows the reference: 0 = distribute, 1 = keep aligned.  With more
-    than one rank only slab layouts along z, ``(0, 1, 1)`` (or None), are accepted here;
-    pencil layouts raise.  Uneven division raises RuntimeError like the reference (:51-57).
+    ``rank_distribution`` follows the reference: 0 = distribute, 1 = keep aligned; the ranks are factored over
+    the distributed axes as MPI.Compute_dims does.  z-slabs ``(0, 1, 1)``, y-slabs ``(1, 0, 1)`` and pencils over
+    z and y ``(0, 0, 1)`` (the reference's default) are served; x stays whole (the transforms and the 16-byte
+    row accesses of the kernels run along it).  ``None`` picks z-slabs here - fewer, larger messages on the
+    point-to-point links of one node - where the reference picks pencils.  Uneven division raises RuntimeError
+    like the reference (:51-57).
     """
 
     def __init__(self, grid_size_z, grid_size_y, grid_size_x, periodic_domain=False, real_t=np.float64,
@@ -72,21 +104,25 @@ class MPIConstruct3D:
         if rank_distribution is None:
             rank_distribution = [0, 1, 1] if self.size > 1 else [0, 0, 1]
         self.rank_distribution = list(rank_distribution)
-        if self.size > 1 and (self.rank_distribution[1] != 1 or self.rank_distribution[2] != 1):
+        if self.size > 1 and self.rank_distribution[2] != 1:
             raise NotImplementedError(
-                f"rank_distribution {self.rank_distribution}: only z-slab decomposition (0, 1, 1) is supported"
+                f"rank_distribution {self.rank_distribution}: the x axis is never divided (slabs and pencils over "
+                "z and y are supported)"
             )
-        self.grid_topology = [self.size, 1, 1]
+        self.grid_topology = compute_dims(self.size, self.rank_distribution) if self.size > 1 else [1, 1, 1]
         self.global_grid_size = np.array((grid_size_z, grid_size_y, grid_size_x))
         if np.any(self.global_grid_size % self.grid_topology):
             logger.error("Cannot divide grid evenly to processors in x, y and/or z directions!")
             raise RuntimeError("Invalid domain decomposition")
         self.local_grid_size = (self.global_grid_size / self.grid_topology).astype(int)
         self.grid = _Grid(self)
-        self.previous_grid_along = np.array([self.rank - 1 if self.rank > 0 else PROC_NULL, PROC_NULL, PROC_NULL])
-        self.next_grid_along = np.array(
-            [self.rank + 1 if self.rank < self.size - 1 else PROC_NULL, PROC_NULL, PROC_NULL]
-        )
+        pz, py = self.grid_topology[0], self.grid_topology[1]
+        rz, ry = self.rank // py, self.rank % py    # Cartesian order of Create_cart
+        self.rank_z, self.rank_y = rz, ry
+        self.previous_grid_along = np.array([self.rank - py if rz > 0 else PROC_NULL,
+                                             self.rank - 1 if ry > 0 else PROC_NULL, PROC_NULL])
+        self.next_grid_along = np.array([self.rank + py if rz < pz - 1 else PROC_NULL,
+                                         self.rank + 1 if ry < py - 1 else PROC_NULL, PROC_NULL])
         self._contexts = {}
 
     def device_context(self, ghost_size):
@@ -94,37 +130,58 @@ class MPIConstruct3D:
         ctx = self._contexts.get(ghost_size)
         if ctx is None:
             ctx = DeviceContext(self.local_grid_size, ghost_size, self.real_t, rank=self.rank, nranks=self.size,
-                                world=self.world)
-            if self.size > 1:
-                ndev = C.c_int(0)
-                call("smi_device_count", C.byref(ndev))
-                mode = os.environ.get("SOPHT_MI_TRANSPORT", "rccl" if ndev.value >= self.size else "host")
-                if mode == "rccl":
-                    # every rank must end up on the same transport: agree on the outcome
-                    try:
-                        ctx.init_rccl()
-                        ok, why = 1.0, ""
-                    except _lib.SophtMIError as exc:
-                        logger.error(f"rank {self.rank}: RCCL initialisation failed ({exc})")
-                        ok, why = 0.0, str(exc)
-                    if self.world.allreduce(ok, "min") < 1.0:
-                        # never silently: a run that was asked to go over RCCL and cannot must not carry on over
-                        # host memory and report figures as if it had (SOPHT_MI_TRANSPORT=host asks for that)
-                        raise RuntimeError(
-                            "RCCL initialisation failed on at least one rank" + (f" (this rank: {why})" if why else "")
-                            + "; set SOPHT_MI_TRANSPORT=host to run over the host-staged transport instead"
-                        )
-                elif mode == "host":
-                    ctx.init_host_staged()
-                else:
-                    raise ValueError(f"SOPHT_MI_TRANSPORT={mode!r}: expected 'rccl' or 'host'")
+                                world=self.world, rank_grid=(self.grid_topology[0], self.grid_topology[1]))
+            self._start_transport(ctx)
             self._contexts[ghost_size] = ctx
         return ctx
 
+    def slab_context(self, ghost_size):
+        """A second context of this rank, over the z-slab decomposition of the same global grid (the unbounded Poisson
+        solve of a pencil decomposition runs there)."""
+        key = ("slab", ghost_size)
+        ctx = self._contexts.get(key)
+        if ctx is None:
+            nz, ny, nx = (int(n) for n in self.global_grid_size)
+            if nz % self.size:
+                raise RuntimeError(f"Invalid domain decomposition: {nz} planes over {self.size} slabs")
+            ctx = DeviceContext((nz // self.size, ny, nx), ghost_size, self.real_t, rank=self.rank, nranks=self.size,
+                                world=self.world)
+            self._start_transport(ctx)
+            self._contexts[key] = ctx
+        return ctx
+
+    def _start_transport(self, ctx):
+        """RCCL (one GPU per rank) or, for tests with ranks that share a GPU, the host-staged transport."""
+        if self.size == 1:
+            return
+        ndev = C.c_int(0)
+        call("smi_device_count", C.byref(ndev))
+        mode = os.environ.get("SOPHT_MI_TRANSPORT", "rccl" if ndev.value >= self.size else "host")
+        if mode == "rccl":
+            # every rank must end up on the same transport: agree on the outcome
+            try:
+                ctx.init_rccl()
+                ok, why = 1.0, ""
+            except _lib.SophtMIError as exc:
+                logger.error(f"rank {self.rank}: RCCL initialisation failed ({exc})")
+                ok, why = 0.0, str(exc)
+            if self.world.allreduce(ok, "min") < 1.0:
+                # never silently: a run that was asked to go over RCCL and cannot must not carry on over
+                # host memory and report figures as if it had (SOPHT_MI_TRANSPORT=host asks for that)
+                raise RuntimeError(
+                    "RCCL initialisation failed on at least one rank" + (f" (this rank: {why})" if why else "")
+                    + "; set SOPHT_MI_TRANSPORT=host to run over the host-staged transport instead"
+                )
+        elif mode == "host":
+            ctx.init_host_staged()
+        else:
+            raise ValueError(f"SOPHT_MI_TRANSPORT={mode!r}: expected 'rccl' or 'host'")
+
 
 class MPIGhostCommunicator3D:
-    """utils/mpi_utils_3d.py:86-1142.  ``full_exchange`` is accepted for compatibility: z-slabs
-    have no diagonal neighbours, and whole ghost planes travel anyway."""
+    """utils/mpi_utils_3d.py:86-1142.  ``full_exchange`` is accepted for compatibility: whole faces travel, the z
+    faces first and then the y faces with the fresh z ghost planes in them, so the edges between two
+    neighbours are always filled (z-slabs have no diagonal neighbours at all)."""
 
     def __init__(self, ghost_size, mpi_construct, full_exchange=True):
         if ghost_size <= 0 or not isinstance(ghost_size, (int, np.integer)):
@@ -156,8 +213,10 @@ class MPIFieldCommunicator3D:
         self.inner_idx = (slice(g, -g),) * 3 if g > 0 else (slice(None),) * 3
 
     def _slab(self, rank):
-        lz = self.mpi_construct.local_grid_size[0]
-        return slice(rank * lz, (rank + 1) * lz)
+        """Index of a rank's block in the global (z, y, x) array."""
+        lz, ly = (int(n) for n in self.mpi_construct.local_grid_size[:2])
+        rz, ry = divmod(rank, int(self.mpi_construct.grid_topology[1]))
+        return (slice(rz * lz, (rz + 1) * lz), slice(ry * ly, (ry + 1) * ly))
 
     def _slab_shape(self):
         return tuple(int(n) for n in self.mpi_construct.local_grid_size)
@@ -219,7 +278,7 @@ class MPILagrangianFieldCommunicator3D:
         self.local_num_lag_nodes = 0
 
     def _compute_lag_nodes_rank_address(self, global_lag_positions):
-        """:1352-1384 (slabs: only the z coordinate selects the owner)."""
+        """:1352-1384."""
         topo = self.mpi_construct.grid_topology
         cz = ((global_lag_positions[2, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[0]).astype(np.int32)
         cy = ((global_lag_positions[1, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[1]).astype(np.int32)
@@ -227,7 +286,7 @@ class MPILagrangianFieldCommunicator3D:
         if np.any(cx >= topo[2]) or np.any(cy >= topo[1]) or np.any(cz >= topo[0]) or np.any(cz < 0):
             logger.error("Lagrangian node is found outside of Eulerian domain!")
             raise RuntimeError("Lagrangian node is found outside of Eulerian domain!")
-        return cz.astype(np.int32)
+        return (cz * int(topo[1]) + cy).astype(np.int32)   # Cartesian rank of block (cz, cy)
 
     def owner_ranks_of(self, global_lag_positions):
         """Owner rank of every node for these positions (:1386-1394: computed on the master rank, broadcast as M

@@ -37,9 +37,19 @@ kw = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, flow_type=flow_typ
           with_free_stream_flow=True, filter_vorticity=with_filter)
 if with_filter:
     kw["filter_setting_dict"] = {"order": 1, "type": "multiplicative"}
-gpu = UnboundedFlowSimulator3D(fused_step=fused, **kw)
+# "pencil": the reference's default decomposition over z and y (utils/mpi_utils_3d.py:32-48); "yslab": slabs along y
+rank_distribution = (0, 0, 1) if "pencil" in sys.argv[4:] else ((1, 0, 1) if "yslab" in sys.argv[4:] else None)
+gpu = UnboundedFlowSimulator3D(fused_step=fused, rank_distribution=rank_distribution, **kw)
 assert gpu.unbounded_poisson_solver.backend == "pruned"
-assert list(gpu.mpi_construct.local_grid_size) == [n[0] // size, n[1], n[2]]
+topo = gpu.mpi_construct.grid_topology
+assert int(np.prod(topo)) == size and topo[2] == 1
+if rank_distribution is None:
+    assert list(topo) == [size, 1, 1]
+elif rank_distribution == (0, 0, 1):
+    assert topo[1] > 1 or size < 4, topo
+else:
+    assert list(topo) == [1, size, 1]
+assert list(gpu.mpi_construct.local_grid_size) == [n[0] // topo[0], n[1] // topo[1], n[2]]
 g = gpu.ghost_size
 comm = MPIFieldCommunicator3D(g, gpu.mpi_construct)
 rng = np.random.default_rng(7)

@@ -60,10 +60,33 @@ def test_topology_and_errors(smi):
     assert c4.previous_grid_along[0] == 0 and c4.next_grid_along[0] == 2
     with pytest.raises(RuntimeError):  # utils/mpi_utils_3d.py:51-57
         MPIConstruct3D(10, 8, 8, world=FakeWorld())
-    with pytest.raises(NotImplementedError):
-        MPIConstruct3D(16, 8, 8, rank_distribution=(0, 0, 1), world=FakeWorld())
+    # pencils over z and y, the reference's default (utils/mpi_utils_3d.py:32-48): rank 1 of a 2 x 2 grid
+    p4 = MPIConstruct3D(16, 8, 8, rank_distribution=(0, 0, 1), world=FakeWorld())
+    assert list(p4.grid_topology) == [2, 2, 1] and list(p4.local_grid_size) == [8, 4, 8]
+    assert list(p4.grid.coords) == [0, 1, 0] and p4.grid.Get_cart_rank([1, 1, 0]) == 3
+    assert list(p4.previous_grid_along) == [PROC_NULL, 0, PROC_NULL] and list(p4.next_grid_along) == [3, PROC_NULL, PROC_NULL]
+    y4 = MPIConstruct3D(16, 8, 8, rank_distribution=(1, 0, 1), world=FakeWorld())
+    assert list(y4.grid_topology) == [1, 4, 1] and list(y4.local_grid_size) == [16, 2, 8]
+    with pytest.raises(NotImplementedError):   # x is never divided
+        MPIConstruct3D(16, 8, 8, rank_distribution=(0, 0, 0), world=FakeWorld())
     with pytest.raises(ValueError):  # utils/mpi_utils.py:17-24
         check_valid_ghost_size_and_kernel_support(ghost_size=1, kernel_support=2)
+
+
+def test_compute_dims_follows_mpi_dims_create():
+    """MPI.Compute_dims as the reference calls it (utils/mpi_utils_3d.py:46-48): balanced, non-increasing."""
+    from sopht_mpi_amd.utils import compute_dims
+
+    assert compute_dims(8, [0, 0, 1]) == [4, 2, 1]
+    assert compute_dims(4, [0, 0, 1]) == [2, 2, 1]
+    assert compute_dims(2, [0, 0, 1]) == [2, 1, 1]
+    assert compute_dims(6, [0, 0, 1]) == [3, 2, 1]
+    assert compute_dims(12, [0, 0, 1]) == [4, 3, 1]
+    assert compute_dims(8, [0, 1, 1]) == [8, 1, 1]
+    assert compute_dims(8, [1, 0, 1]) == [1, 8, 1]
+    assert compute_dims(8, [0, 0, 0]) == [2, 2, 2]
+    with pytest.raises(RuntimeError):
+        compute_dims(8, [3, 0, 1])
 
 
 def test_penalty_factor_tables_match_oracle(smi):
@@ -111,6 +134,14 @@ def test_lagrangian_owner_map(smi):
     bad[2, 3] = 2.5
     with pytest.raises(RuntimeError):
         comm.map_lagrangian_nodes_based_on_position(bad)
+    # pencils: the owner is the Cartesian rank of the (z, y) block (:1352-1384 with a 2 x 2 topology)
+    cp = MPIConstruct3D(*n, real_t=np.float32, rank_distribution=(0, 0, 1), world=FakeWorld())
+    commp = MPILagrangianFieldCommunicator3D(dx, np.float32(dx / 2), cp)
+    commp.map_lagrangian_nodes_based_on_position(pos)
+    shift = np.float32(dx / 2)
+    cz = ((pos[2] - shift) / (dx * 8)).astype(np.int32)
+    cy = ((pos[1] - shift) / (dx * 4)).astype(np.int32)
+    assert np.array_equal(commp.rank_address, cz * 2 + cy) and set(commp.rank_address.tolist()) == {0, 1, 2, 3}
 
 
 def test_2d_lagrangian_and_field_communicators(smi):

@@ -1,4 +1,4 @@
-"""GPU, several ranks: z-slab decomposition (halo exchange, ghost sum, all-to-all FFT transposes,
+"""GPU, several ranks: z-slab and pencil decompositions (halo exchange, ghost sum, all-to-all FFT transposes,
 Lagrangian ownership) against the single-rank oracle.  The ranks share the test box's one GPU,
 so the transport is the host-staged one; the data path through the kernels is the same as
 with RCCL."""
@@ -23,6 +23,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (4, "navier_stokes_with_forcing", "fused", "32x16x32"),
     (4, "navier_stokes", "fused", "192x16x32"),   # a 192-point (radix 8 x 3 x 8) transform across the slabs
     (8, "navier_stokes_with_forcing", "fused", "64x32x64"),  # the largest rank count of the scaling runs: 9 of 65 columns per rank
+    # pencils over z and y (the reference's default decomposition): y faces, edges, the ghost sum's cascade, node
+    # ownership by (z, y) block, the Poisson solve through the slab decomposition
+    (4, "navier_stokes", "unfused", "32x32x32 pencil"),
+    (4, "navier_stokes_with_forcing", "unfused", "64x32x64 pencil"),
+    (4, "navier_stokes_with_forcing", "unfused", "64x32x64 nofilter pencil"),
+    (8, "navier_stokes_with_forcing", "unfused", "64x64x64 pencil"),
+    (2, "navier_stokes_with_forcing", "unfused", "32x32x32 yslab"),
 ])
 def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
     env = dict(os.environ)
