@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-host-transport", action="store_true",
+                    help="several ranks sharing one GPU over the host-staged test transport: checks the multi-rank "
+                         "code path of this script, the figure it prints is not a multi-GPU measurement")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,7 +174,7 @@ def main():
     sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=1e-3,
                                    flow_type="navier_stokes", real_t=real_t, ghost_size=2, penalty_zone_width=2,
                                    poisson_backend=args.poisson)
-    if args.gpus > 1 and sim.ctx.transport != "rccl":
+    if args.gpus > 1 and sim.ctx.transport != "rccl" and not args.rehearse_on_host_transport:
         raise SystemExit(f"bench: {args.gpus} ranks but the transport is {sim.ctx.transport!r}, not rccl; "
                          "refusing to report a multi-GPU figure that did not go over RCCL")
     sim.vorticity_field[...] = synthetic_vorticity(sim.position_field, real_t)
@@ -247,6 +250,8 @@ def main():
         "data": "synthetic",
         "config": config,
     }
+    if args.gpus > 1 and sim.ctx.transport != "rccl":
+        out["invalid"] = "rehearsal over the host-staged transport on a shared GPU, not a multi-GPU measurement"
     out["roofline"] = roofline_from_profile(prof, counters, counters_source)
     out["kernels"] = {k: {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"],
                           "median_ms": float(np.median(v["samples_ms"])) if v["samples_ms"] else None,
