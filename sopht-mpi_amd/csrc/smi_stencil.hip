@@ -1602,7 +1602,15 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   };
   if (!smi_multi_rank(c)) {
     SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
-    launch(0, 1, nchunks);
+    // SMI_FUSED_SPLIT_LAUNCH: the two launches of the overlapped multi-rank schedule below (interior chunks, then the
+    // first and the last chunk) without the exchange between them - a single GPU can then check that they cover the
+    // array exactly like the one launch
+    if (getenv("SMI_FUSED_SPLIT_LAUNCH") && nchunks >= 3) {
+      launch(1, 1, nchunks - 2);
+      launch(0, nchunks - 1, 2);
+    } else {
+      launch(0, 1, nchunks);
+    }
     SMI_LAUNCH_CHECK();
     *ran = 1;
     return 0;

@@ -331,3 +331,9 @@ def test_fused_advection_diffusion_shapes(smi, shape, g, zchunk, monkeypatch):
     _call(smi, "smi_advection_diffusion_update", ctx.handle, dout2.ptr, du.ptr, dw.ptr, dscr.ptr, float(p), float(c))
     assert np.array_equal(dout.get(), dout2.get()), "one pass and two passes must agree bit for bit"
     assert np.array_equal(du.get(), u) and np.array_equal(dw.get(), w), "inputs were modified"
+    # the launch schedule of the overlapped multi-rank path (interior chunks first, then the two outer chunks)
+    monkeypatch.delenv("SMI_NO_FUSED_ADVECT_DIFFUSE")
+    monkeypatch.setenv("SMI_FUSED_SPLIT_LAUNCH", "1")
+    dout3 = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    _call(smi, "smi_advection_diffusion_update", ctx.handle, dout3.ptr, du.ptr, dw.ptr, dscr.ptr, float(p), float(c))
+    assert np.array_equal(dout.get(), dout3.get()), "split launches must cover the array like the single launch"
