@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(kTileThreads) k_diffuse_tiled(T* __restrict__ 
   const int comp = (S.rows + 2) * S.pitch;
   bool core[4];
   {
-    const bool yc = L.own && in_core(L.y, G.py, G.g);
+    const bool yc = L.own && in_core_y(G, L.y);
 #pragma unroll
     for (int e = 0; e < 4; ++e) core[e] = yc && in_core(L.x0 + e, G.px, G.g);
   }
@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
   const int comp = (S.rows + 2) * S.pitch;
   bool core[4];
   {
-    const bool yc = L.own && in_core(L.y, G.py, G.g);
+    const bool yc = L.own && in_core_y(G, L.y);
 #pragma unroll
     for (int e = 0; e < 4; ++e) core[e] = yc && in_core(L.x0 + e, G.px, G.g);
   }
@@ -1294,8 +1294,7 @@ __global__ void __launch_bounds__(kBlock) k_penalise(T* __restrict__ f, Geo G, i
 
 template <typename T>
 bool vec_ok(const smi_ctx* c, const void* a, const void* b) {
-  // the LDS-tiled kernels take their y limits from the array shape: a pencil (inner y faces) runs the plain kernels
-  return c->nranks_y == 1 && c->px % 4 == 0 && ((uintptr_t)a % (4 * sizeof(T))) == 0 && ((uintptr_t)b % (4 * sizeof(T))) == 0 &&
+  return c->px % 4 == 0 && ((uintptr_t)a % (4 * sizeof(T))) == 0 && ((uintptr_t)b % (4 * sizeof(T))) == 0 &&
          (c->vol % 4) == 0;
 }
 
@@ -1585,6 +1584,9 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   SMI_REQUIRE(out != velocity && out != vorticity, "advection-diffusion: output and input must not alias");
   if (c->dtype != SMI_F32 || getenv("SMI_NO_FUSED_ADVECT_DIFFUSE")) return 0;
   if (smi_multi_rank(c) && c->g < 2) return 0;
+  // across an inner y face the advected vorticity of the neighbour's edge row would have to be formed here as it
+  // is for z (Geo::za_lo); a pencil runs the two operators one after the other instead
+  if (c->nranks_y > 1) return 0;
   if (!(vec_ok<float>(c, out, velocity) && vec_ok<float>(c, out, vorticity))) return 0;
   FusedShape S;
   if (!fused_shape<float>(c, S)) return 0;
