@@ -223,7 +223,7 @@ def main():
         "step_hbm_frac": IMPL_BYTES_PER_POINT_STEP[args.dtype] * per_gpu,
         # the same with the HBM bytes the kernels were measured to move (sum over the counter file), when current
         "step_hbm_frac_measured": None,
-        # two byte models of the survey, for reference: the reference's operator sequence with padded FFTs
+        # two other byte models, for comparison: every operator of the reference sequence with padded FFTs
         # (the implementation skips most of that work, so this exceeds 1), and its pruned lower bound
         "step_hbm_frac_model_reference_sequence_1692B": ALG_BYTES_PER_POINT_STEP * per_gpu,
         "step_hbm_frac_model_pruned_lower_bound_660B": MIN_BYTES_PER_POINT_STEP * per_gpu,
