@@ -355,8 +355,9 @@ int smi_set_forcing_support(smi_ctx* ctx, const int* lo_zyx, const int* hi_zyx);
 /* ---- 2D flow path --------------------------------------------------------------------
  * Operators of UnboundedFlowSimulator2D (simulator/flow/flow_simulators_mpi_2d.py:166-298) on
  * ghosted [y][x] arrays of (ny + 2g) * (nx + 2g) reals; vectors are (2, y, x) with component
- * 0 = x.  Single rank: ctx must have been created with nz = 1 and nranks = 1 (its ny, nx and
- * ghost describe the plane). */
+ * 0 = x.  ctx must have been created with nz = 1; its ny, nx and ghost describe the rows of this
+ * rank (utils/mpi_utils_2d.py:33-39: the ranks divide y, x stays whole).  Operators that read neighbours
+ * exchange the ghost rows with the adjacent ranks first, as the reference's wrappers do. */
 typedef struct smi_poisson2d smi_poisson2d;
 /* stencil_ops_2d/diffusion_flux_mpi_2d.py:30-136 */
 int smi2d_diffusion_flux(smi_ctx* ctx, void* flux, const void* field, double prefactor);
@@ -387,6 +388,9 @@ int smi2d_reduce_max(smi_ctx* ctx, const void* field, double* out);
 int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* ctx, const void* greens_host, double dx);
 int smi2d_poisson_destroy(smi_poisson2d* p);
 int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void* rhs);
+/* MPIGhostCommunicator2D.exchange_scalar_field_init / exchange_vector_field_init + exchange_finalise
+ * (utils/mpi_utils_2d.py:286-420) for row slabs: ghost rows <- the neighbours' edge rows, stream ordered */
+int smi2d_halo_exchange(smi_ctx* ctx, void* field, int ncomp);
 /* UnboundedFlowSimulator2D.navier_stokes_timestep / navier_stokes_with_forcing_timestep,
  * flow_simulators_mpi_2d.py:260-298, as one call: forcing may be NULL (no forcing update), free_stream
  * NULL (no free stream), fac_lo / fac_hi as for smi2d_penalise_boundary (ignored when the width is 0). */
@@ -396,7 +400,7 @@ int smi2d_flow_step_ns(smi_ctx* ctx, smi_poisson2d* p, void* vorticity, void* ve
 /* immersed_boundary_ops/EulerianLagrangianGridCommunicatorMPI2D.py:116-520: support (2,4,4,M) and
  * nearest index (2,M) of the nodes, delta-function weights (4,4,M), Eulerian -> Lagrangian
  * interpolation, Lagrangian -> Eulerian spreading (ghost_sum != 0: followed by the ghost sum of
- * :521-652, which on one rank clears the ghost cells). */
+ * :521-652: ghost rows are added to the neighbouring ranks' edge rows, then all ghost cells are cleared). */
 int smi2d_ib_support(smi_ctx* ctx, void* support, void* nearest_index, const void* lag_positions,
                      int64_t m, double dx, double coord_shift);
 int smi2d_ib_weights(smi_ctx* ctx, void* weights, void* support, int64_t m, double dx,

@@ -3,8 +3,12 @@
 //
 // 2D grids are tiny next to the 3D ones (256^2 in the reference's own case), so these
 // kernels are plain one-lane-per-cell kernels: coalesced along x, neighbours through L1/L2.
-// Single rank only.  The context must have been created with nz = 1; its ny, nx and ghost
-// width describe the plane, arrays are (ny + 2g) * (nx + 2g) reals owned by the caller.
+// The context must have been created with nz = 1; its ny, nx and ghost width describe the
+// plane of this rank, arrays are (ny + 2g) * (nx + 2g) reals owned by the caller.  Several ranks
+// divide the rows (the reference's default rank_distribution of MPIConstruct2D, mpi_utils_2d.py:33-39):
+// whole padded rows are contiguous, so ghost rows travel as they lie, and the unbounded Poisson
+// solve gathers the right-hand side on every rank and solves the whole plane there (a 2D plane is
+// a few MB: one all-gather of it costs less than the two transposes of a divided transform).
 //
 // Which cells an operator writes follows the five overlapping boxes of the reference
 // wrappers (diffusion_flux_mpi_2d.py:47-113) and their band zeroing (:116-136), exactly as in
@@ -28,7 +32,11 @@
 
 struct smi_poisson2d {
   smi_ctx* ctx;
-  int ny, nx;
+  int ny, nx;       // the whole plane (ny = rows of all ranks)
+  int ny_local;     // rows of this rank, starting at row0 of the plane
+  int row0;
+  void* gather_send;  // several ranks: this rank's interior rows, one copy per peer for the host-staged transport
+  void* gather_recv;  // several ranks: the interior of the whole plane, (ny, nx)
   hipfftHandle fwd, inv;
   void* real_buf;   // (2ny, 2nx) reals
   void* cplx_buf;   // (2ny, nx + 1) complex
@@ -42,9 +50,10 @@ constexpr int kB = 256;
 struct G2 {
   int py, px, g;
   long long n;  // py * px
+  int ylo, yhi;  // is the low / high y face a physical boundary (false next to another rank's slab of rows)
 };
 
-G2 geo2(const smi_ctx* c) { return G2{c->py, c->px, c->g, (long long)c->py * c->px}; }
+G2 geo2(const smi_ctx* c) { return G2{c->py, c->px, c->g, (long long)c->py * c->px, c->phys_ylo, c->phys_yhi}; }
 int nblocks(long long n) { return (int)((n + kB - 1) / kB); }
 
 __device__ __forceinline__ bool core_s(int a, int p, int g, int s) { return a >= g + s && a <= p - g - s - 1; }
@@ -52,6 +61,10 @@ __device__ __forceinline__ bool face_s(int a, int p, int g, int s) {
   return (a >= g && a <= g + s - 1) || (a >= p - g - s && a <= p - g - 1);
 }
 __device__ __forceinline__ bool ext_s(int a, int p, int s) { return a >= s && a <= p - s - 1; }
+// rows of the zero-banded compute set: s rows are left out next to a physical face, none next to another rank
+__device__ __forceinline__ bool core_y(const G2& G, int y, int s) {
+  return y >= G.g + (G.ylo ? s : 0) && y <= G.py - G.g - 1 - (G.yhi ? s : 0);
+}
 __device__ __forceinline__ bool in_update_set(int y, int x, const G2& G, int s) {
   return (y >= G.g && y <= G.py - G.g - 1 && core_s(x, G.px, G.g, s)) ||
          (ext_s(y, G.py, s) && face_s(x, G.px, G.g, s));
@@ -64,7 +77,7 @@ __global__ void __launch_bounds__(kB) k2_diffusion(T* __restrict__ out, const T*
   if (i >= G.n) return;
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   T v = T(0);
-  if (core_s(y, G.py, G.g, 1) && core_s(x, G.px, G.g, 1))
+  if (core_y(G, y, 1) && core_s(x, G.px, G.g, 1))
     v = c * (f[i + 1] + f[i - 1] + f[i + G.px] + f[i - G.px] - T(4) * f[i]);
   out[i] = ADD ? f[i] + v : v;
 }
@@ -112,7 +125,7 @@ __global__ void __launch_bounds__(kB) k2_outplane_curl(T* __restrict__ curl, con
   if (i >= G.n) return;
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   T u = T(0), v = T(0);
-  if (core_s(y, G.py, G.g, 1) && core_s(x, G.px, G.g, 1)) {
+  if (core_y(G, y, 1) && core_s(x, G.px, G.g, 1)) {
     u = p * (f[i + G.px] - f[i - G.px]);
     v = -p * (f[i + 1] - f[i - 1]);
   }
@@ -138,17 +151,21 @@ struct PenFac2 {
 
 // AXIS 0: one lane per row, AXIS 1: one lane per column (penalise_field_boundary_mpi_2d.py:139-170)
 template <typename T, int AXIS>
-__global__ void __launch_bounds__(kB) k2_penalise(T* __restrict__ f, G2 G, int w, PenFac2 fac) {
+__global__ void __launch_bounds__(kB) k2_penalise(T* __restrict__ f, G2 G, int w, PenFac2 fac, int do_lo, int do_hi) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int lines = AXIS == 0 ? G.py : G.px;
   if (l >= lines) return;
   T* base = AXIS == 0 ? f + (long long)l * G.px : f + l;
   const long long stride = AXIS == 0 ? 1 : G.px;
   const int p = AXIS == 0 ? G.px : G.py;
-  const T lo_src = base[(w - 1) * stride];
-  for (int k = 0; k < w; ++k) base[k * stride] = lo_src * (T)fac.lo[AXIS][k];
-  const T hi_src = base[(p - w) * stride];
-  for (int k = 0; k < w; ++k) base[(p - w + k) * stride] = hi_src * (T)fac.hi[AXIS][k];
+  if (do_lo) {
+    const T lo_src = base[(w - 1) * stride];
+    for (int k = 0; k < w; ++k) base[k * stride] = lo_src * (T)fac.lo[AXIS][k];
+  }
+  if (do_hi) {
+    const T hi_src = base[(p - w) * stride];
+    for (int k = 0; k < w; ++k) base[(p - w + k) * stride] = hi_src * (T)fac.hi[AXIS][k];
+  }
 }
 
 template <typename T>
@@ -202,18 +219,129 @@ __global__ void __launch_bounds__(kB) k2_scale(T* __restrict__ a, T s, long long
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] *= s;
 }
+// rows row0 .. row0 + ny - 1 of the doubled plane -> the interior of this rank's solution array
 template <typename T>
 __global__ void __launch_bounds__(kB) k2_extract(T* __restrict__ sol, const T* __restrict__ dbl, int ny, int nx,
-                                                int g, int px) {
+                                                int g, int px, int row0) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)ny * nx) return;
   const int y = (int)(i / nx), x = (int)(i - (long long)y * nx);
-  sol[(long long)(y + g) * px + x + g] = dbl[(long long)y * 2 * nx + x];
+  sol[(long long)(y + g) * px + x + g] = dbl[(long long)(y + row0) * 2 * nx + x];
+}
+// interior of a ghosted array -> dense (ny, nx)
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_pack_interior(T* __restrict__ dense, const T* __restrict__ f, int ny, int nx,
+                                                      int g, int px) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)ny * nx) return;
+  const int y = (int)(i / nx), x = (int)(i - (long long)y * nx);
+  dense[i] = f[(long long)(y + g) * px + x + g];
 }
 
 int require_2d(const smi_ctx* c, const char* who) {
   SMI_REQUIRE(c, "%s: null context", who);
-  SMI_REQUIRE(c->nz == 1 && c->nranks == 1, "%s: the 2D operators need a single-rank context created with nz = 1", who);
+  SMI_REQUIRE(c->nz == 1, "%s: the 2D operators need a context created with nz = 1", who);
+  return 0;
+}
+
+// MPIGhostCommunicator2D (utils/mpi_utils_2d.py:87-421) for slabs of rows: whole padded rows are contiguous, so the
+// first / last g interior rows travel as they lie into the neighbour's ghost rows.
+int halo2(smi_ctx* c, void* field, int ncomp) {
+  if (c->nranks == 1) return 0;
+  const size_t es = smi_elem_size(c), row = (size_t)c->px * es, n = (size_t)c->py * c->px * es;
+  const size_t bytes = (size_t)c->g * row;
+  const bool lo = c->rank_y > 0, hi = c->rank_y < c->nranks_y - 1;
+  for (int k = 0; k < ncomp; ++k) {
+    char* base = (char*)field + k * n;
+    char* send_lo = base + (size_t)c->g * row;
+    char* recv_lo = base;
+    char* send_hi = base + (size_t)(c->py - 2 * c->g) * row;
+    char* recv_hi = base + (size_t)(c->py - c->g) * row;
+    if (c->sendrecv_cb) {
+      SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+      int rc = c->sendrecv_cb(c->exchange_user, lo ? c->rank - 1 : -1, hi ? c->rank + 1 : -1, send_lo, send_hi, recv_lo,
+                              recv_hi, bytes);
+      SMI_REQUIRE(rc == 0, "2D halo exchange callback failed (%d)", rc);
+    } else {
+      SMI_REQUIRE(c->comm_ready, "2D halo exchange across ranks needs smi_comm_init or a send-receive callback");
+      SMI_CHECK_NCCL(ncclGroupStart());
+      if (lo) {
+        SMI_CHECK_NCCL(ncclSend(send_lo, bytes, ncclChar, c->rank - 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv(recv_lo, bytes, ncclChar, c->rank - 1, c->comm, c->stream));
+      }
+      if (hi) {
+        SMI_CHECK_NCCL(ncclSend(send_hi, bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv(recv_hi, bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+      }
+      SMI_CHECK_NCCL(ncclGroupEnd());
+    }
+  }
+  return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_add(T* __restrict__ dst, const T* __restrict__ src, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+// Ghost sum across the row slabs (EulerianLagrangianGridCommunicatorMPI2D.py:523-620): what the spread left in my
+// ghost rows belongs to the neighbour's edge rows.  My low ghost rows are added to the previous rank's last g
+// interior rows, my high ghost rows to the next rank's first g interior rows.
+int ghost_sum2(smi_ctx* c, void* field, int ncomp) {
+  if (c->nranks == 1) return 0;
+  const size_t es = smi_elem_size(c), row = (size_t)c->px * es, n = (size_t)c->py * c->px * es;
+  const size_t bytes = (size_t)c->g * row;
+  const long long cells = (long long)c->g * c->px;
+  SMI_REQUIRE((size_t)ncomp * bytes <= c->halo_cap, "2D ghost sum: staging buffer too small");
+  const bool lo = c->rank_y > 0, hi = c->rank_y < c->nranks_y - 1;
+  for (int k = 0; k < ncomp; ++k) {
+    char* base = (char*)field + k * n;
+    char* send_lo = base;
+    char* send_hi = base + (size_t)(c->py - c->g) * row;
+    char* recv_lo = (char*)c->halo_recv[0] + k * bytes;
+    char* recv_hi = (char*)c->halo_recv[1] + k * bytes;
+    if (c->sendrecv_cb) {
+      SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+      int rc = c->sendrecv_cb(c->exchange_user, lo ? c->rank - 1 : -1, hi ? c->rank + 1 : -1, send_lo, send_hi, recv_lo,
+                              recv_hi, bytes);
+      SMI_REQUIRE(rc == 0, "2D ghost sum callback failed (%d)", rc);
+    } else {
+      SMI_REQUIRE(c->comm_ready, "2D ghost sum across ranks needs smi_comm_init or a send-receive callback");
+      SMI_CHECK_NCCL(ncclGroupStart());
+      if (lo) {
+        SMI_CHECK_NCCL(ncclSend(send_lo, bytes, ncclChar, c->rank - 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv(recv_lo, bytes, ncclChar, c->rank - 1, c->comm, c->stream));
+      }
+      if (hi) {
+        SMI_CHECK_NCCL(ncclSend(send_hi, bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+        SMI_CHECK_NCCL(ncclRecv(recv_hi, bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+      }
+      SMI_CHECK_NCCL(ncclGroupEnd());
+    }
+    SMI_DISPATCH(c, {
+      if (lo) k2_add<T><<<nblocks(cells), kB, 0, c->stream>>>((T*)(base + (size_t)c->g * row), (const T*)recv_lo, cells);
+      if (hi)
+        k2_add<T><<<nblocks(cells), kB, 0, c->stream>>>((T*)(base + (size_t)(c->py - 2 * c->g) * row), (const T*)recv_hi,
+                                                        cells);
+    });
+    SMI_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// Every rank's block of `bytes` bytes -> all blocks in rank order on every rank.  `send` holds room for one copy of
+// the block per rank: the host-staged transport only knows an all-to-all, which gets the block replicated.
+int allgather2(smi_ctx* c, void* send, void* recv, size_t bytes) {
+  if (c->alltoall_cb) {
+    for (int r = 1; r < c->nranks; ++r)
+      SMI_CHECK_HIP(hipMemcpyAsync((char*)send + r * bytes, send, bytes, hipMemcpyDeviceToDevice, c->stream));
+    int rc = c->alltoall_cb(c->exchange_user, send, recv, bytes);
+    SMI_REQUIRE(rc == 0, "2D all-gather callback failed (%d)", rc);
+    return 0;
+  }
+  SMI_REQUIRE(c->comm_ready, "2D Poisson solve across ranks needs smi_comm_init or a transport callback");
+  SMI_CHECK_NCCL(ncclAllGather(send, recv, bytes, ncclChar, c->comm, c->stream));
   return 0;
 }
 
@@ -231,6 +359,7 @@ int fft_forward(smi_poisson2d* p, void* real_in, void* cplx_out) {
 extern "C" int smi2d_diffusion_flux(smi_ctx* c, void* flux, const void* field, double prefactor) {
   SMI_CHECK(require_2d(c, "smi2d_diffusion_flux"));
   SMI_REQUIRE(flux && field && flux != field, "smi2d_diffusion_flux: bad argument");
+  SMI_CHECK(halo2(c, (void*)field, 1));
   G2 G = geo2(c);
   SMI_DISPATCH(c, { k2_diffusion<T, false><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (T)prefactor, G); });
   SMI_LAUNCH_CHECK();
@@ -250,6 +379,8 @@ extern "C" int smi2d_advection_timestep_eno3(smi_ctx* c, void* field, void* flux
   SMI_CHECK(require_2d(c, "smi2d_advection_timestep_eno3"));
   SMI_REQUIRE(field && flux && velocity && flux != field, "smi2d_advection_timestep_eno3: bad argument");
   SMI_REQUIRE(c->g >= 2, "smi2d_advection_timestep_eno3: kernel support 2 needs ghost_size >= 2 (got %d)", c->g);
+  SMI_CHECK(halo2(c, field, 1));
+  SMI_CHECK(halo2(c, (void*)velocity, 2));
   G2 G = geo2(c);
   SMI_DISPATCH(c, {
     k2_advection_flux<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (const T*)velocity,
@@ -266,6 +397,8 @@ extern "C" int smi2d_advection_flux_eno3(smi_ctx* c, void* flux, const void* fie
   SMI_CHECK(require_2d(c, "smi2d_advection_flux_eno3"));
   SMI_REQUIRE(field && flux && velocity && flux != field, "smi2d_advection_flux_eno3: bad argument");
   SMI_REQUIRE(c->g >= 2, "smi2d_advection_flux_eno3: kernel support 2 needs ghost_size >= 2 (got %d)", c->g);
+  SMI_CHECK(halo2(c, (void*)field, 1));
+  SMI_CHECK(halo2(c, (void*)velocity, 2));
   G2 G = geo2(c);
   SMI_DISPATCH(c, {
     k2_advection_flux<T, true><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (const T*)velocity,
@@ -278,6 +411,7 @@ extern "C" int smi2d_advection_flux_eno3(smi_ctx* c, void* flux, const void* fie
 extern "C" int smi2d_outplane_field_curl(smi_ctx* c, void* curl, const void* field, double prefactor) {
   SMI_CHECK(require_2d(c, "smi2d_outplane_field_curl"));
   SMI_REQUIRE(curl && field && curl != field, "smi2d_outplane_field_curl: bad argument");
+  SMI_CHECK(halo2(c, (void*)field, 1));
   G2 G = geo2(c);
   SMI_DISPATCH(c, { k2_outplane_curl<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)curl, (const T*)field, (T)prefactor, G); });
   SMI_LAUNCH_CHECK();
@@ -288,6 +422,7 @@ extern "C" int smi2d_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vo
                                                             double prefactor) {
   SMI_CHECK(require_2d(c, "smi2d_update_vorticity_from_velocity_forcing"));
   SMI_REQUIRE(vorticity && forcing && vorticity != forcing, "smi2d_update_vorticity_from_velocity_forcing: bad argument");
+  SMI_CHECK(halo2(c, (void*)forcing, 2));
   G2 G = geo2(c);
   SMI_DISPATCH(c, {
     k2_update_vorticity<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)vorticity, (const T*)forcing, (T)prefactor, G);
@@ -313,8 +448,9 @@ extern "C" int smi2d_penalise_boundary(smi_ctx* c, void* field, int width, const
     }
   G2 G = geo2(c);
   SMI_DISPATCH(c, {
-    k2_penalise<T, 0><<<nblocks(G.py), kB, 0, c->stream>>>((T*)field, G, w, fac);
-    k2_penalise<T, 1><<<nblocks(G.px), kB, 0, c->stream>>>((T*)field, G, w, fac);
+    k2_penalise<T, 0><<<nblocks(G.py), kB, 0, c->stream>>>((T*)field, G, w, fac, 1, 1);
+    if (c->phys_ylo || c->phys_yhi)
+      k2_penalise<T, 1><<<nblocks(G.px), kB, 0, c->stream>>>((T*)field, G, w, fac, c->phys_ylo, c->phys_yhi);
   });
   SMI_LAUNCH_CHECK();
   return 0;
@@ -371,8 +507,11 @@ extern "C" int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* c, const void*
   SMI_CHECK(require_2d(c, "smi2d_poisson_create"));
   SMI_REQUIRE(out && greens_host, "smi2d_poisson_create: bad argument");
   smi_poisson2d* p = new smi_poisson2d();
+  memset(p, 0, sizeof(*p));
   p->ctx = c;
-  p->ny = c->ny;
+  p->ny_local = c->ny;
+  p->row0 = c->rank_y * c->ny;
+  p->ny = c->ny * c->nranks;
   p->nx = c->nx;
   const size_t es = smi_elem_size(c);
   const size_t nreal = 4 * (size_t)p->ny * p->nx, ncplx = 2 * (size_t)p->ny * (p->nx + 1);
@@ -381,6 +520,10 @@ extern "C" int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* c, const void*
   SMI_CHECK_HIP(hipMalloc(&p->real_buf, nreal * es));
   SMI_CHECK_HIP(hipMalloc(&p->cplx_buf, ncplx * 2 * es));
   SMI_CHECK_HIP(hipMalloc(&p->ghat, ncplx * 2 * es));
+  if (c->nranks > 1) {
+    SMI_CHECK_HIP(hipMalloc(&p->gather_send, (size_t)p->ny * p->nx * es));
+    SMI_CHECK_HIP(hipMalloc(&p->gather_recv, (size_t)p->ny * p->nx * es));
+  }
   SMI_CHECK_FFT2(hipfftPlan2d(&p->fwd, 2 * p->ny, 2 * p->nx, f32 ? HIPFFT_R2C : HIPFFT_D2Z));
   SMI_CHECK_FFT2(hipfftPlan2d(&p->inv, 2 * p->ny, 2 * p->nx, f32 ? HIPFFT_C2R : HIPFFT_Z2D));
   SMI_CHECK_FFT2(hipfftSetStream(p->fwd, c->stream));
@@ -405,6 +548,8 @@ extern "C" int smi2d_poisson_destroy(smi_poisson2d* p) {
   hipFree(p->real_buf);
   hipFree(p->cplx_buf);
   hipFree(p->ghat);
+  if (p->gather_send) hipFree(p->gather_send);
+  if (p->gather_recv) hipFree(p->gather_recv);
   delete p;
   return 0;
 }
@@ -413,16 +558,26 @@ extern "C" int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void*
   SMI_REQUIRE(p && solution && rhs, "smi2d_poisson_solve: bad argument");
   smi_ctx* c = p->ctx;
   const long long nreal = 4LL * p->ny * p->nx, ncplx = 2LL * p->ny * (p->nx + 1);
+  const long long nlocal = (long long)p->ny_local * p->nx;
   SMI_DISPATCH(c, {
-    k2_pad_load<T><<<nblocks(nreal), kB, 0, c->stream>>>((T*)p->real_buf, (const T*)rhs, p->ny, p->nx, c->g, c->px);
+    if (c->nranks > 1) {
+      // the whole right-hand side on every rank, then the single-rank solve of the plane
+      k2_pack_interior<T><<<nblocks(nlocal), kB, 0, c->stream>>>((T*)p->gather_send, (const T*)rhs, p->ny_local, p->nx,
+                                                                 c->g, c->px);
+      SMI_CHECK(allgather2(c, p->gather_send, p->gather_recv, (size_t)nlocal * sizeof(T)));
+      k2_pad_load<T><<<nblocks(nreal), kB, 0, c->stream>>>((T*)p->real_buf, (const T*)p->gather_recv, p->ny, p->nx, 0,
+                                                           p->nx);
+    } else {
+      k2_pad_load<T><<<nblocks(nreal), kB, 0, c->stream>>>((T*)p->real_buf, (const T*)rhs, p->ny, p->nx, c->g, c->px);
+    }
     SMI_CHECK((fft_forward<T>(p, p->real_buf, p->cplx_buf)));
     k2_cmul<T><<<nblocks(ncplx), kB, 0, c->stream>>>((T*)p->cplx_buf, (const T*)p->ghat, ncplx);
     if (sizeof(T) == 4)
       SMI_CHECK_FFT2(hipfftExecC2R(p->inv, (hipfftComplex*)p->cplx_buf, (hipfftReal*)p->real_buf));
     else
       SMI_CHECK_FFT2(hipfftExecZ2D(p->inv, (hipfftDoubleComplex*)p->cplx_buf, (hipfftDoubleReal*)p->real_buf));
-    k2_extract<T><<<nblocks((long long)p->ny * p->nx), kB, 0, c->stream>>>((T*)solution, (const T*)p->real_buf, p->ny,
-                                                                          p->nx, c->g, c->px);
+    k2_extract<T><<<nblocks(nlocal), kB, 0, c->stream>>>((T*)solution, (const T*)p->real_buf, p->ny_local, p->nx, c->g,
+                                                         c->px, p->row0);
   });
   SMI_LAUNCH_CHECK();
   return 0;
@@ -453,11 +608,12 @@ struct Ib2 {
   int py, px, g;
   long long n;
   double dx, shift;
-  long long ls;  // local substart coordinate shift = -ghost on the single rank
+  long long lsx, lsy;  // mpi_local_substart_coord_shift = first cell of this rank's block - ghost (x, y)
 };
 
 Ib2 make_ib2(const smi_ctx* c, double dx, double shift) {
-  return Ib2{c->py, c->px, c->g, (long long)c->py * c->px, dx, shift, -(long long)c->g};
+  return Ib2{c->py, c->px, c->g, (long long)c->py * c->px, dx, shift, -(long long)c->g,
+             (long long)c->rank_y * c->ny - c->g};
 }
 
 struct Delta2 {
@@ -490,15 +646,15 @@ __global__ void __launch_bounds__(256) k2_ib_support(double* __restrict__ suppor
   if (node >= m) return;
   const int lane = (int)(gid & 15), ox = (lane & 3) - kW2 + 1, oy = (lane >> 2) - kW2 + 1;
   const double X = pos[node], Y = pos[m + node];
-  const long long ix = (long long)py_floordiv2(X - G.shift, G.dx) - G.ls;
-  const long long iy = (long long)py_floordiv2(Y - G.shift, G.dx) - G.ls;
+  const long long ix = (long long)py_floordiv2(X - G.shift, G.dx) - G.lsx;
+  const long long iy = (long long)py_floordiv2(Y - G.shift, G.dx) - G.lsy;
   if (lane == 0) {
     index[node] = ix;
     index[m + node] = iy;
   }
   const long long cell = (long long)lane * m + node;  // support[c][dy][dx][node]
-  support[cell] = (double)(ix + ox + G.ls) * G.dx + G.shift - X;
-  support[16 * m + cell] = (double)(iy + oy + G.ls) * G.dx + G.shift - Y;
+  support[cell] = (double)(ix + ox + G.lsx) * G.dx + G.shift - X;
+  support[16 * m + cell] = (double)(iy + oy + G.lsy) * G.dx + G.shift - Y;
 }
 
 __global__ void __launch_bounds__(256) k2_ib_weights(double* __restrict__ weights, double* __restrict__ support,
@@ -613,7 +769,8 @@ extern "C" int smi2d_ib_interpolate(smi_ctx* c, void* lag_field, const void* eul
   return 0;
 }
 
-// Spreading followed by the single-rank ghost sum (every neighbour is PROC_NULL: ghosts are cleared)
+// Spreading followed by the ghost sum: ghost rows are added to the neighbouring ranks' edge rows, then every ghost
+// cell is cleared (on a single rank every neighbour is PROC_NULL and only the clearing remains)
 extern "C" int smi2d_ib_spread(smi_ctx* c, void* eul_field, const void* lag_field, const void* weights,
                                const void* nearest_index, int64_t m, int ncomp, int ghost_sum) {
   SMI_CHECK(require_2d(c, "smi2d_ib_spread"));
@@ -627,10 +784,21 @@ extern "C" int smi2d_ib_spread(smi_ctx* c, void* eul_field, const void* lag_fiel
       k2_ib_spread<T><<<nblocks(16 * m), 256, 0, c->stream>>>((T*)eul_field, (const double*)lag_field,
                                                             (const double*)weights, (const long long*)nearest_index,
                                                             m, ncomp, G);
-    if (ghost_sum) k2_clear_ghosts<T><<<nblocks(P.n * ncomp), kB, 0, c->stream>>>((T*)eul_field, P, ncomp);
   });
   SMI_LAUNCH_CHECK();
+  if (ghost_sum) {
+    SMI_CHECK(ghost_sum2(c, eul_field, ncomp));
+    SMI_DISPATCH(c, { k2_clear_ghosts<T><<<nblocks(P.n * ncomp), kB, 0, c->stream>>>((T*)eul_field, P, ncomp); });
+    SMI_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+// MPIGhostCommunicator2D.exchange_scalar_field_init / exchange_vector_field_init (utils/mpi_utils_2d.py:286-420)
+extern "C" int smi2d_halo_exchange(smi_ctx* c, void* field, int ncomp) {
+  SMI_CHECK(require_2d(c, "smi2d_halo_exchange"));
+  SMI_REQUIRE(field && ncomp >= 1, "smi2d_halo_exchange: bad argument");
+  return halo2(c, field, ncomp);
 }
 
 // One 2D Navier-Stokes step sequenced inside the library (flow_simulators_mpi_2d.py:260-298): the

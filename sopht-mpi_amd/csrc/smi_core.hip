@@ -42,8 +42,8 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   SMI_REQUIRE(ghost >= 1 && ghost <= 8, "smi_ctx_create: ghost size %d must be in [1, 8]", ghost);
   SMI_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "smi_ctx_create: invalid rank %d of %d", rank,
               nranks);
-  // nz == 1 (single rank) is the plane of the 2D operators, which ignore the z extent
-  SMI_REQUIRE(((nz == 1 && nranks == 1) || nz >= 2 * ghost) && ny >= 2 * ghost && nx >= 2 * ghost,
+  // nz == 1 is the plane of the 2D operators, which ignore the z extent (several ranks: slabs of rows)
+  SMI_REQUIRE((nz == 1 || nz >= 2 * ghost) && ny >= 2 * ghost && nx >= 2 * ghost,
               "smi_ctx_create: local grid %d %d %d smaller than 2*ghost", nz, ny, nx);
   SMI_CHECK_HIP(hipSetDevice(device));
   SMI_CHECK(smi_pruned_scratch_init(device));
@@ -69,6 +69,16 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   c->rank_y = 0;
   c->nranks_y = 1;
   c->phys_ylo = c->phys_yhi = 1;
+  if (nz == 1 && nranks > 1) {
+    // 2D: the ranks divide the rows (mpi_utils_2d.py:9-84 with the default rank_distribution)
+    c->rank_z = 0;
+    c->nranks_z = 1;
+    c->rank_y = rank;
+    c->nranks_y = nranks;
+    c->phys_zlo = c->phys_zhi = 1;
+    c->phys_ylo = rank == 0;
+    c->phys_yhi = rank == nranks - 1;
+  }
   // staging for the ghost sum (and the host-staged plane upload): 3 components of g planes
   c->halo_cap = (size_t)3 * ghost * c->plane * smi_elem_size(c);
   const int rc = ctx_allocate(c);

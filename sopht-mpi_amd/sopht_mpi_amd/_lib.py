@@ -128,6 +128,7 @@ SIGNATURES = {
     "smi2d_poisson_create": [_pp, _p, _p, _d],
     "smi2d_poisson_destroy": [_p],
     "smi2d_poisson_solve": [_p, _p, _p],
+    "smi2d_halo_exchange": [_p, _p, _i],
     "smi2d_flow_step_ns": [_p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _i, _dp, _dp, _dp],
     "smi2d_ib_support": [_p, _p, _p, _p, C.c_int64, _d, _d],
     "smi2d_ib_weights": [_p, _p, _p, C.c_int64, _d, _i],

@@ -162,8 +162,9 @@ def gen_add_fixed_val_pyst_kernel_2d(real_t, field_type="scalar", ctx=None):
 
 
 class UnboundedPoissonSolverMPI2D:
-    """poisson_solver_2d/UnboundedPoissonSolverMPI2D.py:20-153 on one GPU (hipFFT 2D transforms,
-    fused pad / multiply / crop kernels)."""
+    """poisson_solver_2d/UnboundedPoissonSolverMPI2D.py:20-153 (hipFFT 2D transforms, fused pad / multiply / crop
+    kernels).  Across row slabs every rank gathers the right-hand side of the whole plane and solves it: a 2D plane is
+    a few MB, one all-gather of it costs less than the two transposes of a divided transform."""
 
     def __init__(self, grid_size_y, grid_size_x, mpi_construct, ghost_size, x_range=1.0, real_t=np.float64):
         self.mpi_construct = mpi_construct

@@ -5,7 +5,7 @@ import numpy as np
 from ... import _lib
 from ..._lib import call, i64array
 from ...device import EMPTY_SUPPORT, DeviceField, as_ptr
-from ...utils import MPILagrangianFieldCommunicator3D
+from ...utils import MPILagrangianFieldCommunicator2D, MPILagrangianFieldCommunicator3D
 
 _KERNEL_TYPES = {"cosine": _lib.SMI_DELTA_COSINE, "peskin": _lib.SMI_DELTA_PESKIN}
 
@@ -78,8 +78,9 @@ class EulerianLagrangianGridCommunicatorMPI3D:
 
 
 class EulerianLagrangianGridCommunicatorMPI2D:
-    """EulerianLagrangianGridCommunicatorMPI2D.py:7-113 on one GPU: index (2, M) int64 (x, y), support
-    (2, 4, 4, M) float64, weights (4, 4, M) float64, Lagrangian fields (2, M) or (M,)."""
+    """EulerianLagrangianGridCommunicatorMPI2D.py:7-113: index (2, M) int64 (x, y), support
+    (2, 4, 4, M) float64, weights (4, 4, M) float64, Lagrangian fields (2, M) or (M,).  The library takes the
+    first cell of this rank's rows from the context (row slabs: ``rank * local rows``, x starts at 0)."""
 
     def __init__(self, dx, eul_grid_coord_shift, interp_kernel_width, real_t, mpi_construct, ghost_size,
                  n_components=1, interp_kernel_type="cosine"):
@@ -101,7 +102,8 @@ class EulerianLagrangianGridCommunicatorMPI2D:
         self.coord_shift = float(eul_grid_coord_shift)
         self.n_components = n_components
         self.kernel_type = _KERNEL_TYPES[interp_kernel_type]
-        self.mpi_substart_idx = np.zeros(2, dtype=np.int64)
+        # :41-46, x, y order
+        self.mpi_substart_idx = np.flip(mpi_construct.grid.coords * mpi_construct.local_grid_size).astype(np.int64)
         self.mpi_local_substart_coord_shift = self.mpi_substart_idx - ghost_size
 
     def local_eulerian_grid_support_of_lagrangian_grid_kernel(self, local_eul_grid_support_of_lag_grid,
@@ -129,14 +131,15 @@ class EulerianLagrangianGridCommunicatorMPI2D:
 
     def lagrangian_to_eulerian_grid_interpolation_kernel(self, eul_grid_field, lag_grid_field, interp_weights,
                                                          nearest_eul_grid_index_to_lag_grid):
-        """:99-113: spread, then the ghost sum (one rank: the ghost cells are cleared)."""
+        """:99-113: spread, then the ghost sum (ghost rows are added to the neighbouring ranks' edge rows, then
+        the ghost cells are cleared)."""
         call("smi2d_ib_spread", self.ctx.handle, as_ptr(eul_grid_field), as_ptr(lag_grid_field),
              as_ptr(interp_weights), as_ptr(nearest_eul_grid_index_to_lag_grid), lag_grid_field.shape[-1],
              self.n_components, 1)
 
 
 class VirtualBoundaryForcingMPI:
-    """VirtualBoundaryForcingMPI.py:21-459.  3D as described below; 2D (one GPU) runs the
+    """VirtualBoundaryForcingMPI.py:21-459.  3D as described below; 2D runs the
     communicator's four kernels one after the other and forms the penalty force with a fifth.
 
     Global Lagrangian arrays (``global_lag_grid_*``) are host numpy arrays owned by the master
@@ -152,7 +155,7 @@ class VirtualBoundaryForcingMPI:
         if grid_dim != 2 and grid_dim != 3:
             raise ValueError("Invalid grid dimensions for virtual boundary forcing!")
         self.grid_dim = grid_dim
-        if grid_dim == 2:
+        if grid_dim == 2 and mpi_construct.size == 1:
             assume_data_locality = True  # one rank owns every node
         self.virtual_boundary_stiffness_coeff = virtual_boundary_stiffness_coeff
         self.virtual_boundary_damping_coeff = virtual_boundary_damping_coeff
@@ -180,7 +183,8 @@ class VirtualBoundaryForcingMPI:
         )
         self.ctx = self.eul_lag_grid_communicator.ctx
         if not assume_data_locality:
-            self.mpi_lagrangian_field_communicator = MPILagrangianFieldCommunicator3D(
+            lag_comm_cls = MPILagrangianFieldCommunicator3D if grid_dim == 3 else MPILagrangianFieldCommunicator2D
+            self.mpi_lagrangian_field_communicator = lag_comm_cls(
                 eul_grid_dx=dx, eul_grid_coord_shift=eul_grid_coord_shift, mpi_construct=mpi_construct,
                 master_rank=master_rank, real_t=np.float64,
             )

@@ -1,4 +1,4 @@
-"""UnboundedFlowSimulator2D on one MI355X: the constructor, attributes and methods users of
+"""UnboundedFlowSimulator2D (one MI355X, or row slabs over several): the constructor, attributes and methods users of
 sopht_mpi/simulator/flow/flow_simulators_mpi_2d.py:20-328 rely on.  Same construction as the 3D simulator
 (tables of fields and operators, a step as a list of stages); the 2D Navier-Stokes step advects with the ENO3
 flux instead of the rotational form and has no vorticity filter."""
@@ -15,7 +15,7 @@ _NS = UnboundedFlowSimulatorBase.VORTICITY_FLOW_TYPES
 
 
 class UnboundedFlowSimulator2D(UnboundedFlowSimulatorBase):
-    """2D unbounded flow simulator (single GPU)."""
+    """2D unbounded flow simulator."""
 
     grid_dim = 2
     FLOW_TYPES = _ALL
@@ -138,4 +138,5 @@ class UnboundedFlowSimulator2D(UnboundedFlowSimulatorBase):
 
     def get_max_vorticity(self):
         """flow_simulators_mpi_2d.py:323-328."""
-        return self.real_t(self._reduce("smi2d_reduce_max", as_ptr(self.vorticity_field)))
+        local_max = self._reduce("smi2d_reduce_max", as_ptr(self.vorticity_field))
+        return self.real_t(self.ctx.allreduce(float(local_max), "max"))

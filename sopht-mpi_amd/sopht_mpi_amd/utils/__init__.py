@@ -151,31 +151,35 @@ class MPIConstruct3D:
         return ctx
 
     def _start_transport(self, ctx):
-        """RCCL (one GPU per rank) or, for tests with ranks that share a GPU, the host-staged transport."""
-        if self.size == 1:
-            return
-        ndev = C.c_int(0)
-        call("smi_device_count", C.byref(ndev))
-        mode = os.environ.get("SOPHT_MI_TRANSPORT", "rccl" if ndev.value >= self.size else "host")
-        if mode == "rccl":
-            # every rank must end up on the same transport: agree on the outcome
-            try:
-                ctx.init_rccl()
-                ok, why = 1.0, ""
-            except _lib.SophtMIError as exc:
-                logger.error(f"rank {self.rank}: RCCL initialisation failed ({exc})")
-                ok, why = 0.0, str(exc)
-            if self.world.allreduce(ok, "min") < 1.0:
-                # never silently: a run that was asked to go over RCCL and cannot must not carry on over
-                # host memory and report figures as if it had (SOPHT_MI_TRANSPORT=host asks for that)
-                raise RuntimeError(
-                    "RCCL initialisation failed on at least one rank" + (f" (this rank: {why})" if why else "")
-                    + "; set SOPHT_MI_TRANSPORT=host to run over the host-staged transport instead"
-                )
-        elif mode == "host":
-            ctx.init_host_staged()
-        else:
-            raise ValueError(f"SOPHT_MI_TRANSPORT={mode!r}: expected 'rccl' or 'host'")
+        _start_transport(self, ctx)
+
+
+def _start_transport(construct, ctx):
+    """RCCL (one GPU per rank) or, for tests with ranks that share a GPU, the host-staged transport."""
+    if construct.size == 1:
+        return
+    ndev = C.c_int(0)
+    call("smi_device_count", C.byref(ndev))
+    mode = os.environ.get("SOPHT_MI_TRANSPORT", "rccl" if ndev.value >= construct.size else "host")
+    if mode == "rccl":
+        # every rank must end up on the same transport: agree on the outcome
+        try:
+            ctx.init_rccl()
+            ok, why = 1.0, ""
+        except _lib.SophtMIError as exc:
+            logger.error(f"rank {construct.rank}: RCCL initialisation failed ({exc})")
+            ok, why = 0.0, str(exc)
+        if construct.world.allreduce(ok, "min") < 1.0:
+            # never silently: a run that was asked to go over RCCL and cannot must not carry on over
+            # host memory and report figures as if it had (SOPHT_MI_TRANSPORT=host asks for that)
+            raise RuntimeError(
+                "RCCL initialisation failed on at least one rank" + (f" (this rank: {why})" if why else "")
+                + "; set SOPHT_MI_TRANSPORT=host to run over the host-staged transport instead"
+            )
+    elif mode == "host":
+        ctx.init_host_staged()
+    else:
+        raise ValueError(f"SOPHT_MI_TRANSPORT={mode!r}: expected 'rccl' or 'host'")
 
 
 class MPIGhostCommunicator3D:
@@ -210,12 +214,15 @@ class MPIFieldCommunicator3D:
         self.ghost_size = ghost_size
         self.master_rank = master_rank
         g = ghost_size
-        self.inner_idx = (slice(g, -g),) * 3 if g > 0 else (slice(None),) * 3
+        dim = self.grid_dim = mpi_construct.grid_dim
+        self.inner_idx = (slice(g, -g),) * dim if g > 0 else (slice(None),) * dim
 
     def _slab(self, rank):
         """Index of a rank's block in the global (z, y, x) array."""
         lz, ly = (int(n) for n in self.mpi_construct.local_grid_size[:2])
         rz, ry = divmod(rank, int(self.mpi_construct.grid_topology[1]))
+        if self.grid_dim == 2:   # (y, x): rows divided, x whole
+            return (slice(rz * lz, (rz + 1) * lz),)
         return (slice(rz * lz, (rz + 1) * lz), slice(ry * ly, (ry + 1) * ly))
 
     def _slab_shape(self):
@@ -250,13 +257,13 @@ class MPIFieldCommunicator3D:
             world.sendrecv({self.master_rank: mine}, {})
 
     def scatter_global_vector_field(self, local_vector_field, global_vector_field):
-        for c in range(3):
+        for c in range(self.grid_dim):
             self.scatter_global_scalar_field(
                 local_vector_field[c], None if global_vector_field is None else global_vector_field[c]
             )
 
     def gather_local_vector_field(self, global_vector_field, local_vector_field):
-        for c in range(3):
+        for c in range(self.grid_dim):
             self.gather_local_scalar_field(
                 None if global_vector_field is None else global_vector_field[c], local_vector_field[c]
             )
@@ -266,8 +273,9 @@ class MPILagrangianFieldCommunicator3D:
     """utils/mpi_utils_3d.py:1309-1459: which slab owns each Lagrangian node, and scatter /
     gather of (3, M) Lagrangian arrays between the master rank and the owners."""
 
+    grid_dim = 3
+
     def __init__(self, eul_grid_dx, eul_grid_coord_shift, mpi_construct, master_rank=0, real_t=np.float64):
-        self.grid_dim = 3
         self.mpi_construct = mpi_construct
         self.master_rank = master_rank
         self.rank = mpi_construct.rank
@@ -360,16 +368,17 @@ __all__ = [
 ]
 
 
-# --------------------------------------------------------------------------- 2D (single rank)
+# --------------------------------------------------------------------------- 2D
 class _Grid2D(_Grid):
     def __init__(self, construct):
         self._c = construct
-        self.coords = np.array([0, 0])
+        self.coords = np.array([construct.rank, 0])
 
 
 class MPIConstruct2D:
-    """utils/mpi_utils_2d.py:9-84.  The 2D path runs on one GPU: 2D grids are a few hundred
-    cells wide, far below what one device holds; more than one rank raises RuntimeError."""
+    """utils/mpi_utils_2d.py:9-84.  Several ranks divide the rows (``rank_distribution`` ``[0, 1]``, the reference's
+    default: y distributed, x aligned for the transforms); x is never divided.  Uneven division raises RuntimeError
+    like the reference (:52-58)."""
 
     def __init__(self, grid_size_y, grid_size_x, periodic_domain=False, real_t=np.float64, rank_distribution=None,
                  world=None):
@@ -380,30 +389,39 @@ class MPIConstruct2D:
         self.periodic_domain = False
         self.world = get_world() if world is None else world
         self.size, self.rank = self.world.size, self.world.rank
-        if self.size > 1:
-            logger.error("The 2D path is single rank")
-            raise RuntimeError("Invalid domain decomposition")
         self.rank_distribution = [0, 1] if rank_distribution is None else list(rank_distribution)
-        self.grid_topology = [1, 1]
+        if self.size > 1 and self.rank_distribution[1] != 1:
+            raise NotImplementedError(
+                f"rank_distribution {self.rank_distribution}: the x axis is never divided (row slabs are supported)"
+            )
+        self.grid_topology = [self.size, 1]
         self.global_grid_size = np.array((grid_size_y, grid_size_x))
-        self.local_grid_size = self.global_grid_size.copy()
+        if np.any(self.global_grid_size % self.grid_topology):
+            logger.error("Cannot divide grid evenly to processors in x and/or y directions!")
+            raise RuntimeError("Invalid domain decomposition")
+        self.local_grid_size = (self.global_grid_size / self.grid_topology).astype(int)
         self.grid = _Grid2D(self)
-        self.previous_grid_along = np.array([PROC_NULL, PROC_NULL])
-        self.next_grid_along = np.array([PROC_NULL, PROC_NULL])
+        last = self.size - 1
+        self.previous_grid_along = np.array([self.rank - 1 if self.rank > 0 else PROC_NULL, PROC_NULL])
+        self.next_grid_along = np.array([self.rank + 1 if self.rank < last else PROC_NULL, PROC_NULL])
         self._contexts = {}
 
     def device_context(self, ghost_size):
         ctx = self._contexts.get(ghost_size)
         if ctx is None:
             ny, nx = (int(n) for n in self.local_grid_size)
-            ctx = DeviceContext((1, ny, nx), ghost_size, self.real_t, rank=0, nranks=1, world=self.world)
+            ctx = DeviceContext((1, ny, nx), ghost_size, self.real_t, rank=self.rank, nranks=self.size,
+                                world=self.world)
             ctx.padded_shape_2d = (ny + 2 * ghost_size, nx + 2 * ghost_size)
+            _start_transport(self, ctx)
             self._contexts[ghost_size] = ctx
         return ctx
 
 
 class MPIGhostCommunicator2D:
-    """utils/mpi_utils_2d.py:87-421: with one rank every neighbour is PROC_NULL, nothing moves."""
+    """utils/mpi_utils_2d.py:87-421 for row slabs: the first / last ``ghost_size`` interior rows go to the neighbours'
+    ghost rows (whole padded rows, contiguous in memory).  There are no diagonal neighbours, so ``full_exchange``
+    changes nothing (the reference's own remark, :112-116)."""
 
     def __init__(self, ghost_size, mpi_construct, full_exchange=True):
         if ghost_size <= 0 or not isinstance(ghost_size, (int, np.integer)):
@@ -414,59 +432,31 @@ class MPIGhostCommunicator2D:
         self.ctx = mpi_construct.device_context(self.ghost_size)
 
     def exchange_scalar_field_init(self, local_field):
-        pass
+        call("smi2d_halo_exchange", self.ctx.handle, as_ptr(local_field), 1)
 
     def exchange_vector_field_init(self, local_vector_field):
-        pass
+        call("smi2d_halo_exchange", self.ctx.handle, as_ptr(local_vector_field), local_vector_field.shape[0])
 
     def exchange_finalise(self):
-        pass
+        """Exchanges are stream-ordered with the kernels that consume them; nothing to wait for."""
 
 
-class MPIFieldCommunicator2D:
-    """utils/mpi_utils_2d.py:424-568 on the single rank of the 2D path: the global host array
-    and the interior of the device field are the same cells."""
+class MPIFieldCommunicator2D(MPIFieldCommunicator3D):
+    """utils/mpi_utils_2d.py:424-568: scatter / gather of whole (y, x) fields between a global host array on
+    ``master_rank`` and the row slabs on the devices (interiors only)."""
 
     def __init__(self, ghost_size, mpi_construct, master_rank=0):
         if ghost_size < 0 or not isinstance(ghost_size, (int, np.integer)):
             raise ValueError(f"Ghost size {ghost_size} needs to be an integer >= 0 for field communication.")
-        self.mpi_construct = mpi_construct
-        self.ghost_size = int(ghost_size)
-        self.master_rank = master_rank
-        g = self.ghost_size
-        self.inner_idx = (slice(g, -g),) * 2 if g > 0 else (slice(None),) * 2
-
-    def scatter_global_scalar_field(self, local_field, global_field):
-        host = local_field.get()
-        host[self.inner_idx] = np.asarray(global_field)
-        local_field.set(host)
-
-    def gather_local_scalar_field(self, global_field, local_field):
-        global_field[...] = local_field.get()[self.inner_idx]
-
-    def scatter_global_vector_field(self, local_vector_field, global_vector_field):
-        for c in range(2):
-            self.scatter_global_scalar_field(local_vector_field[c], global_vector_field[c])
-
-    def gather_local_vector_field(self, global_vector_field, local_vector_field):
-        for c in range(2):
-            self.gather_local_scalar_field(global_vector_field[c], local_vector_field[c])
+        super().__init__(int(ghost_size), mpi_construct, master_rank)
 
 
-class MPILagrangianFieldCommunicator2D:
-    """utils/mpi_utils_2d.py:571-712 on one rank: every node inside the domain belongs to rank 0;
-    a node outside raises (the reference logs and aborts the job, :628-640)."""
+class MPILagrangianFieldCommunicator2D(MPILagrangianFieldCommunicator3D):
+    """utils/mpi_utils_2d.py:571-712: which row slab owns each Lagrangian node, and scatter / gather of (2, M)
+    Lagrangian arrays between the master rank and the owners.  A node outside the domain raises (the reference logs
+    and aborts the job, :626-632)."""
 
-    def __init__(self, eul_grid_dx, eul_grid_coord_shift, mpi_construct, master_rank=0, real_t=np.float64):
-        self.grid_dim = 2
-        self.mpi_construct = mpi_construct
-        self.master_rank = master_rank
-        self.rank = mpi_construct.rank
-        self.eul_subblock_dx = eul_grid_dx * mpi_construct.local_grid_size
-        self.eul_grid_coord_shift = eul_grid_coord_shift
-        self.real_t = real_t
-        self.rank_address = np.zeros(0, dtype=np.int32)
-        self.local_num_lag_nodes = 0
+    grid_dim = 2
 
     def _compute_lag_nodes_rank_address(self, global_lag_positions):
         topo = self.mpi_construct.grid_topology
@@ -475,21 +465,7 @@ class MPILagrangianFieldCommunicator2D:
         if np.any(cx >= topo[1]) or np.any(cy >= topo[0]) or np.any(cx < 0) or np.any(cy < 0):
             logger.error("Lagrangian node is found outside of Eulerian domain!")
             raise RuntimeError("Lagrangian node is found outside of Eulerian domain!")
-        return np.zeros(global_lag_positions.shape[-1], dtype=np.int32)
-
-    def map_lagrangian_nodes_based_on_position(self, global_lag_positions):
-        if global_lag_positions.shape[0] != self.grid_dim:
-            raise RuntimeError(f"global_lag_positions needs to be shape ({self.grid_dim}, ...)")
-        self.rank_address = self._compute_lag_nodes_rank_address(global_lag_positions)
-        self.local_nodes_idx = np.where(self.rank_address == self.rank)
-        self.local_num_lag_nodes = int(self.rank_address.shape[0])
-        self.slave_ranks_containing_lag_nodes = set()
-
-    def scatter_global_field(self, local_lag_field, global_lag_field):
-        local_lag_field[...] = np.asarray(global_lag_field)
-
-    def gather_local_field(self, global_lag_field, local_lag_field):
-        global_lag_field[...] = np.asarray(local_lag_field)
+        return (cy * int(topo[1]) + cx).astype(np.int32)
 
 
 __all__ += ["MPIConstruct2D", "MPIGhostCommunicator2D", "MPIFieldCommunicator2D", "MPILagrangianFieldCommunicator2D"]

@@ -169,6 +169,34 @@ def test_2d_lagrangian_and_field_communicators(smi):
         MPIFieldCommunicator2D(ghost_size=-1, mpi_construct=c)
 
 
+def test_2d_row_slab_topology_and_owner_map(smi):
+    """utils/mpi_utils_2d.py:9-84 and :611-637 for several ranks: the rows are divided, x stays whole, a node belongs
+    to the rank whose rows hold it (half-open intervals)."""
+    from sopht_mpi_amd.utils import PROC_NULL, MPIConstruct2D, MPILagrangianFieldCommunicator2D
+    from sopht_mpi_amd.world import SingleWorld
+
+    class FakeWorld(SingleWorld):
+        rank, size = 2, 4
+
+    c = MPIConstruct2D(32, 24, real_t=np.float32, world=FakeWorld())
+    assert c.rank_distribution == [0, 1] and list(c.grid_topology) == [4, 1]
+    assert list(c.local_grid_size) == [8, 24] and list(c.grid.coords) == [2, 0]
+    assert list(c.previous_grid_along) == [1, PROC_NULL] and list(c.next_grid_along) == [3, PROC_NULL]
+    with pytest.raises(RuntimeError):           # :52-58
+        MPIConstruct2D(30, 24, world=FakeWorld())
+    with pytest.raises(NotImplementedError):    # x is never divided
+        MPIConstruct2D(32, 24, rank_distribution=[1, 0], world=FakeWorld())
+    dx = np.float32(1.0 / 24)
+    comm = MPILagrangianFieldCommunicator2D(dx, np.float32(dx / 2), c)
+    pos = np.random.default_rng(2).uniform(0.05, 0.95, (2, 200)) * np.array([1.0, 32 / 24]).reshape(2, 1)
+    pos[1, 0] = 8 * float(dx) + float(dx) / 2    # exactly on the boundary between the rows of rank 0 and rank 1
+    comm.map_lagrangian_nodes_based_on_position(pos)
+    want = ((pos[1] - np.float32(dx / 2)) / (dx * 8)).astype(np.int32)
+    assert np.array_equal(comm.rank_address, want) and comm.rank_address[0] == 1
+    assert set(comm.rank_address.tolist()) == {0, 1, 2, 3}
+    assert comm.local_num_lag_nodes == int(np.sum(want == 2))
+
+
 def test_forcing_grid_api(smi):
     from sopht_mpi_amd.simulator import EmptyForcingGrid, PrescribedForcingGrid
 

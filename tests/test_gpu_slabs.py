@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _failure_digest(out):
+    """The lines of a failed multi-rank run that name its errors (the rank that failed first is often not the last
+    to print), then the tail of both streams."""
+    errors = [line for line in (out.stdout + out.stderr).splitlines()
+              if "Error" in line and "ChildFailedError" not in line and "ConnectionResetError" not in line]
+    return "\n".join(errors[:20]) + "\n----\n" + out.stdout[-2000:] + out.stderr[-4000:]
+
+
 @pytest.mark.parametrize("nranks,flow_type,mode,grid", [
     (2, "navier_stokes", "fused", "32x16x32"),
     # without the vorticity filter: the one-pass advection + diffusion leaves its result in the buffer array and the
@@ -39,7 +47,29 @@ def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + nranks),
            os.path.join(ROOT, "tests", "_slab_worker.py"), flow_type, mode] + grid.split()
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert out.returncode == 0, _failure_digest(out)
+    for r in range(nranks):
+        assert f"rank {r} ok" in out.stdout
+
+
+@pytest.mark.parametrize("nranks,flow_type,mode,grid", [
+    (2, "navier_stokes", "fused", "32x48"),
+    (2, "passive_scalar", "unfused", "32x48"),
+    (4, "navier_stokes_with_forcing", "fused", "64x48"),
+    (4, "navier_stokes_with_forcing", "unfused", "64x48 double"),
+    (8, "navier_stokes_with_forcing", "fused", "64x64"),
+])
+def test_row_slab_2d_flow_matches_oracle(nranks, flow_type, mode, grid):
+    """The 2D path over slabs of rows (the reference's default MPIConstruct2D decomposition) against the single-rank
+    oracle on the whole plane."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["SOPHT_MI_TRANSPORT"] = "host"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(29700 + nranks),
+           os.path.join(ROOT, "tests", "_rows_worker_2d.py"), flow_type, mode] + grid.split()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, _failure_digest(out)
     for r in range(nranks):
         assert f"rank {r} ok" in out.stdout
 
