@@ -187,7 +187,7 @@ def test_2d_row_slab_topology_and_owner_map(smi):
     with pytest.raises(NotImplementedError):    # x is never divided
         MPIConstruct2D(32, 24, rank_distribution=[1, 0], world=FakeWorld())
     dx = np.float32(1.0 / 24)
-    comm = MPILagrangianFieldCommunicator2D(dx, np.float32(dx / 2), c)
+    comm = MPILagrangianFieldCommunicator2D(dx, np.float32(dx / 2), c, master_rank=2)   # this (fake) rank maps
     pos = np.random.default_rng(2).uniform(0.05, 0.95, (2, 200)) * np.array([1.0, 32 / 24]).reshape(2, 1)
     pos[1, 0] = 8 * float(dx) + float(dx) / 2    # exactly on the boundary between the rows of rank 0 and rank 1
     comm.map_lagrangian_nodes_based_on_position(pos)
