@@ -143,6 +143,36 @@ def cpu_baseline(grid, steps, warmup):
     }
 
 
+class Watchdog:
+    """Multi-rank runs only: a collective that never completes (a rank missing, a link down) would otherwise hold
+    every rank and the launcher until somebody kills them.  Each phase gets a deadline; when one passes, the rank
+    says where it was and leaves with a non-zero status, which makes the launcher take the other ranks down."""
+
+    def __init__(self, enabled, rank):
+        self.enabled, self.rank, self.timer = enabled, rank, None
+
+    def phase(self, name, seconds):
+        import threading
+
+        self.cancel()
+        if not self.enabled:
+            return
+
+        def fire():
+            sys.stderr.write(f"bench: rank {self.rank} did not finish '{name}' within {seconds} s; giving up\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +198,8 @@ def main():
     from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
     from sopht_mpi_amd.world import get_world
 
+    watchdog = Watchdog(args.gpus > 1, int(os.environ.get("RANK", "0")))
+    watchdog.phase("rendezvous, context and RCCL set-up", 300)
     world = get_world()
     rank = world.rank
     n, real_t = args.grid, (np.float32 if args.dtype == "f32" else np.float64)
@@ -177,10 +209,12 @@ def main():
     if args.gpus > 1 and sim.ctx.transport != "rccl" and not args.rehearse_on_host_transport:
         raise SystemExit(f"bench: {args.gpus} ranks but the transport is {sim.ctx.transport!r}, not rccl; "
                          "refusing to report a multi-GPU figure that did not go over RCCL")
+    watchdog.phase("initial condition and first velocity solve", 300)
     sim.vorticity_field[...] = synthetic_vorticity(sim.position_field, real_t)
     sim.compute_flow_velocity(free_stream_velocity=None)
     dt = float(sim.compute_stable_timestep())  # CFL 0.1, fixed over the timed region
 
+    watchdog.phase("warm-up and timed steps", 120 + 2 * (args.warmup + args.steps))
     for _ in range(args.warmup):
         sim.time_step(dt=dt)
     sim.ctx.sync()
@@ -197,6 +231,7 @@ def main():
     prof = _lib.prof_collect(sim.ctx)
     _lib.call("smi_prof_enable", sim.ctx.handle, 0)
     max_vort = float(sim.get_max_vorticity())
+    watchdog.cancel()
     if not np.isfinite(max_vort):
         raise SystemExit("bench: vorticity became non-finite")
 
