@@ -469,3 +469,7 @@ class MPILagrangianFieldCommunicator2D(MPILagrangianFieldCommunicator3D):
 
 
 __all__ += ["MPIConstruct2D", "MPIGhostCommunicator2D", "MPIFieldCommunicator2D", "MPILagrangianFieldCommunicator2D"]
+
+from .mpi_io import CosseratRodMPIIO, MPIIO  # noqa: E402  (needs the classes above)
+
+__all__ += ["MPIIO", "CosseratRodMPIIO"]

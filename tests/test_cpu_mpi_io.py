@@ -1,0 +1,277 @@
+"""Checkpoint output (sopht_mpi/utils/mpi_io.py): the HDF5 subset writer / reader against the layouts of the HDF5
+file format specification, and ``MPIIO`` save -> load round trips shaped like the reference's own tests
+(tests/test_utils/test_mpi_io_3d.py, test_mpi_io_2d.py), for one rank and for several ranks writing their blocks
+of one file.  No HDF5 library exists in this environment: what is pinned here is the specification's byte layout of
+every structure the writer emits, and that the reader recovers every value."""
+import struct
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+from sopht_mpi_amd.utils import h5lite
+from sopht_mpi_amd.world import SingleWorld
+
+
+def test_message_encodings_follow_the_specification():
+    # IEEE double, little endian: class 1 version 1, bit field 0x20 0x3f 0x00, size 8; properties: bit offset 0,
+    # precision 64, exponent at bit 52 (11 bits), mantissa at bit 0 (52 bits), bias 1023
+    assert h5lite.encode_datatype(np.float64) == bytes.fromhex("11203f00" "08000000" "0000" "4000" "340b" "0034" "ff030000")
+    assert h5lite.encode_datatype(np.float32) == bytes.fromhex("11201f00" "04000000" "0000" "2000" "1708" "0017" "7f000000")
+    # signed 64-bit integer: class 0 version 1, bit 3 = signed; properties: bit offset 0, precision 64
+    assert h5lite.encode_datatype(np.int64) == bytes.fromhex("10080000" "08000000" "0000" "4000")
+    for dt in (np.float32, np.float64, np.int64, np.int32, np.uint8):
+        assert h5lite.decode_datatype(h5lite.encode_datatype(dt)) == np.dtype(dt)
+    # simple dataspace, version 1: version, rank, flags, 5 reserved bytes, then the dimensions as 8-byte lengths
+    assert h5lite.encode_dataspace((3, 5)) == bytes([1, 2, 0, 0, 0, 0, 0, 0]) + struct.pack("<QQ", 3, 5)
+    assert h5lite.decode_dataspace(h5lite.encode_dataspace((1, 8, 12, 16))) == (1, 8, 12, 16)
+    assert h5lite.decode_dataspace(h5lite.encode_dataspace(())) == ()
+    name, value = h5lite.decode_attribute(h5lite.encode_attribute("time", np.float64(0.1)))
+    assert name == "time" and value == 0.1 and value.dtype == np.float64
+    name, value = h5lite.decode_attribute(h5lite.encode_attribute("grid_size", np.array([8, 12, 16])))
+    assert name == "grid_size" and value.tolist() == [8, 12, 16]
+    with pytest.raises(ValueError):
+        h5lite.encode_datatype(np.complex64)
+
+
+def test_file_structures_follow_the_specification(tmp_path):
+    path = str(tmp_path / "layout.h5")
+    w = h5lite.Writer()
+    w.root.attrs["time"] = 0.25
+    grp = w.root.create_group("Eulerian")
+    data = np.arange(24, dtype=np.float32).reshape(1, 2, 3, 4)
+    dset = grp.create_dataset("omega", data.shape, np.float32, data=data)
+    grp.create_dataset("alpha", (5,), np.int64, data=np.arange(5))
+    end = w.write(path)
+    raw = open(path, "rb").read()
+    assert len(raw) == end
+    # superblock, version 0: signature, versions, 8-byte offsets and lengths, node sizes, addresses
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n" and raw[8:16] == bytes([0, 0, 0, 0, 0, 8, 8, 0])
+    leaf_k, internal_k, flags = struct.unpack_from("<HHI", raw, 16)
+    assert (leaf_k, internal_k, flags) == (h5lite.LEAF_K, h5lite.INTERNAL_K, 0)
+    base, free, eof, driver = struct.unpack_from("<QQQQ", raw, 24)
+    assert (base, free, eof, driver) == (0, h5lite.UNDEF, end, h5lite.UNDEF)
+    # root symbol table entry: name offset 0, header address, cache type 1 with the B-tree and heap addresses
+    name_off, header, cache, _ = struct.unpack_from("<QQII", raw, 56)
+    btree, heap = struct.unpack_from("<QQ", raw, 80)
+    assert name_off == 0 and cache == 1 and header == 96
+    # version 1 object header of the root: 2 messages (symbol table, attribute), reference count 1
+    version, _, nmsg, refs, size = struct.unpack_from("<BBHII", raw, header)
+    assert (version, nmsg, refs) == (1, 2, 1)
+    kind, msize, _flags = struct.unpack_from("<HHB", raw, header + 16)
+    assert kind == 0x11 and msize == 16 and struct.unpack_from("<QQ", raw, header + 24) == (btree, heap)
+    assert header + 16 + size == btree and btree % 8 == 0
+    # B-tree node: group node, leaf level, one entry, no siblings; key 0 / child 0 / key 1
+    assert raw[btree:btree + 4] == b"TREE"
+    ntype, level, used, left, right = struct.unpack_from("<BBHQQ", raw, btree + 4)
+    assert (ntype, level, used, left, right) == (0, 0, 1, h5lite.UNDEF, h5lite.UNDEF)
+    key0, snod, key1 = struct.unpack_from("<QQQ", raw, btree + 24)
+    assert heap == btree + 24 + 8 * (2 * internal_k + 1) + 8 * 2 * internal_k
+    # local heap: header, then the data segment with the empty name first and a free block at its end
+    assert raw[heap:heap + 4] == b"HEAP" and raw[heap + 4] == 0
+    seg_size, free_head, seg = struct.unpack_from("<QQQ", raw, heap + 8)
+    assert seg == heap + 32 and raw[seg:seg + 8] == bytes(8)
+    assert raw[seg + key1:seg + key1 + 9] == b"Eulerian\0" and key0 == 0
+    nxt, fsize = struct.unpack_from("<QQ", raw, seg + free_head)
+    assert nxt == h5lite.HEAP_FREE_NULL and free_head + fsize == seg_size and fsize >= 16
+    # symbol table node with one entry pointing at the group's header (cache type 1)
+    assert raw[snod:snod + 4] == b"SNOD" and raw[snod + 4] == 1 and struct.unpack_from("<H", raw, snod + 6)[0] == 1
+    e_name, e_header, e_cache, _ = struct.unpack_from("<QQII", raw, snod + 8)
+    assert e_name == key1 and e_cache == 1
+    # the dataset: contiguous layout message (version 3, class 1) holding the address and size of its bytes
+    r = h5lite.Reader(path)
+    info = r["Eulerian/omega"]
+    assert info.address == dset.data_address and info.address % 8 == 0
+    assert raw[info.address:info.address + data.nbytes] == data.tobytes()
+    assert r.visit() == ["Eulerian", "Eulerian/alpha", "Eulerian/omega"]   # links sorted by name in the node
+    assert r.attrs["time"] == 0.25
+    assert np.array_equal(r["Eulerian/omega"][...], data) and r["Eulerian/alpha"][...].tolist() == [0, 1, 2, 3, 4]
+    assert np.array_equal(r["Eulerian/omega"][:, 1:, :2], data[:, 1:, :2])
+    with pytest.raises(KeyError):
+        r["Eulerian/missing"]
+    open(str(tmp_path / "junk.h5"), "wb").write(b"not an hdf5 file at all")
+    with pytest.raises(ValueError):
+        h5lite.Reader(str(tmp_path / "junk.h5"))
+
+
+def test_many_links_and_empty_groups(tmp_path):
+    path = str(tmp_path / "many.h5")
+    w = h5lite.Writer()
+    w.root.create_group("Empty")
+    g = w.root.create_group("Fields")
+    names = [f"field_{k:02d}" for k in range(40)] + ["Z", "a", "velocity_0"]
+    for k, name in enumerate(names):
+        g.create_dataset(name, (3,), np.float64, data=np.full(3, float(k)))
+    with pytest.raises(ValueError):
+        g.create_dataset("a", (1,), np.float64)
+    w.write(path)
+    r = h5lite.Reader(path)
+    assert r["Empty"].links == {} and sorted(r["Fields"].links) == sorted(names)
+    for k, name in enumerate(names):
+        assert r[f"Fields/{name}"][...].tolist() == [float(k)] * 3
+
+
+class SequentialWorld(SingleWorld):
+    """Several 'ranks' run one after the other in this process, rank 0 first: what rank 0 broadcasts is kept for
+    the others."""
+
+    board = {}
+
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+        self.calls = 0
+
+    def bcast_object(self, obj, root=0):
+        key = self.calls
+        self.calls += 1
+        if self.rank == root:
+            self.board[key] = obj
+        return self.board[key]
+
+
+@pytest.mark.parametrize("ghost_size", [1, 2])
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("rank_distribution,size", [((0, 1, 1), 1), ((0, 1, 1), 4), ((1, 0, 1), 2), ((0, 0, 1), 4)])
+def test_eulerian_fields_round_trip_3d(smi, tmp_path, ghost_size, real_t, rank_distribution, size):
+    """test_mpi_io_3d.py:11-250: scalar and vector fields, every decomposition served here, both precisions."""
+    from sopht_mpi_amd.utils import MPIIO, MPIConstruct3D
+
+    rng = np.random.default_rng(3)
+    grid_size = np.array([8, 12, 16])
+    dx = 1.0 / grid_size[2]
+    path = str(tmp_path / "eulerian.h5")
+    g = ghost_size
+    glob_s = rng.random(tuple(grid_size)).astype(real_t)
+    glob_v = rng.random((3,) + tuple(grid_size)).astype(real_t)
+    SequentialWorld.board = {}
+
+    def rank_io(rank, scalar, vector):
+        c = MPIConstruct3D(*grid_size, real_t=real_t, rank_distribution=rank_distribution,
+                           world=SequentialWorld(rank, size))
+        io = MPIIO(mpi_construct=c, real_dtype=real_t)
+        io.define_eulerian_grid(origin=(dx / 2) * np.ones(3), dx=dx * np.ones(3), grid_size=grid_size, ghost_size=g)
+        io.add_as_eulerian_fields_for_io(scalar_field=scalar, vector_field=vector)
+        return c, io
+
+    def block(c):
+        lz, ly, lx = (int(n) for n in c.local_grid_size)
+        rz, ry = int(c.grid.coords[0]), int(c.grid.coords[1])
+        return (slice(rz * lz, (rz + 1) * lz), slice(ry * ly, (ry + 1) * ly), slice(0, lx))
+
+    inner = (slice(g, -g),) * 3
+    for rank in range(size):
+        c = MPIConstruct3D(*grid_size, real_t=real_t, rank_distribution=rank_distribution,
+                           world=SequentialWorld(rank, size))
+        padded = tuple(int(n) + 2 * g for n in c.local_grid_size)
+        scalar, vector = rng.random(padded).astype(real_t), rng.random((3,) + padded).astype(real_t)
+        scalar[inner] = glob_s[block(c)]
+        vector[(slice(None),) + inner] = glob_v[(slice(None),) + block(c)]
+        _, io = rank_io(rank, scalar, vector)
+        io.save(h5_file_name=path, time=0.1)
+    r = h5lite.Reader(path)
+    assert np.array_equal(r["Eulerian/Scalar/scalar_field"][...], glob_s[None])
+    for k in range(3):
+        assert np.array_equal(r[f"Eulerian/Vector/vector_field_{k}"][...], glob_v[k][None])
+    assert r["Eulerian/Parameters"].attrs["grid_size"].tolist() == grid_size.tolist()
+    np.testing.assert_allclose(r["Eulerian/Parameters"].attrs["dx"], dx)
+    assert "Lagrangian" in r and r["Lagrangian"].links == {}
+    for rank in range(size):
+        c = MPIConstruct3D(*grid_size, real_t=real_t, rank_distribution=rank_distribution,
+                           world=SequentialWorld(rank, size))
+        padded = tuple(int(n) + 2 * g for n in c.local_grid_size)
+        scalar, vector = np.zeros(padded, dtype=real_t), np.zeros((3,) + padded, dtype=real_t)
+        _, io = rank_io(rank, scalar, vector)
+        assert io.load(h5_file_name=path) == 0.1
+        assert np.array_equal(scalar[inner], glob_s[block(c)])
+        assert np.array_equal(vector[(slice(None),) + inner], glob_v[(slice(None),) + block(c)])
+        assert not scalar[0].any() and not vector[:, :, 0].any()      # ghost cells are left alone
+    # the XDMF description names every dataset of the file
+    xdmf = ET.parse(str(tmp_path / "eulerian_eulerian.xmf")).getroot()
+    items = [e.text.strip() for e in xdmf.iter("DataItem") if e.get("Format") == "HDF"]
+    assert sorted(i.split(":/")[1] for i in items) == sorted(p for p in r.visit() if p.count("/") == 2)
+    topo = next(xdmf.iter("Topology"))
+    assert topo.get("TopologyType") == "3DCORECTMesh" and topo.get("Dimensions").split() == ["8", "12", "16"]
+    assert next(xdmf.iter("Time")).get("Value") == "0.1"
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+def test_eulerian_and_lagrangian_round_trip_2d(smi, tmp_path, real_t):
+    """test_mpi_io_2d.py: a 2D field is stored as a one-cell-thick (1, ny, nx) dataset; Lagrangian grids with scalar
+    and vector fields, with and without a connection."""
+    from sopht_mpi_amd.utils import MPIIO, MPIConstruct2D
+
+    rng = np.random.default_rng(4)
+    grid_size, g, n = np.array([12, 16]), 2, 7
+    dx = 1.0 / 16
+    path = str(tmp_path / "fields2d.h5")
+    c = MPIConstruct2D(*grid_size, real_t=real_t, world=SingleWorld())
+
+    def make(scalar, vector, lag_grid, lag_scalar, lag_vector, drift):
+        io = MPIIO(mpi_construct=c, real_dtype=real_t)
+        io.define_eulerian_grid(origin=(dx / 2) * np.ones(2), dx=dx * np.ones(2), grid_size=grid_size, ghost_size=g)
+        io.add_as_eulerian_fields_for_io(vorticity=scalar, velocity=vector)
+        io.add_as_lagrangian_fields_for_io(lagrangian_grid=lag_grid, lagrangian_grid_master_rank=0,
+                                           lagrangian_grid_name="body", lagrangian_grid_connect=True,
+                                           scalar_lag=lag_scalar, vector_lag=lag_vector)
+        io.add_as_lagrangian_fields_for_io(lagrangian_grid=drift, lagrangian_grid_master_rank=0)
+        return io
+
+    padded = tuple(int(k) + 2 * g for k in grid_size)
+    saved = [rng.random(padded).astype(real_t), rng.random((2,) + padded).astype(real_t),
+             rng.random((2, n)).astype(real_t), rng.random(n).astype(real_t), rng.random((2, n)).astype(real_t),
+             rng.random((2, 3)).astype(real_t)]
+    make(*saved).save(path, time=1.5)
+    r = h5lite.Reader(path)
+    assert r["Eulerian/Scalar/vorticity"].shape == (1, 12, 16)
+    assert r["Lagrangian/body/Grid"].shape == (n, 2) and r["Lagrangian/body/Connection"][...].tolist() == list(range(n))
+    assert np.array_equal(r["Lagrangian/body/Vector/vector_lag"][...], saved[4].T)
+    assert "Lagrangian/Lagrangian_grid_0/Grid" in r
+    loaded = [np.zeros_like(a) for a in saved]
+    assert make(*loaded).load(path) == 1.5
+    inner = (slice(g, -g),) * 2
+    assert np.array_equal(loaded[0][inner], saved[0][inner])
+    assert np.array_equal(loaded[1][(slice(None),) + inner], saved[1][(slice(None),) + inner])
+    for a, b in zip(loaded[2:], saved[2:]):
+        assert np.array_equal(a, b)
+    body = ET.parse(str(tmp_path / "fields2d_body.xmf")).getroot()
+    assert next(body.iter("Topology")).get("TopologyType") == "Polyline"
+    assert next(body.iter("Geometry")).get("GeometryType") == "XY"
+    free = ET.parse(str(tmp_path / "fields2d_Lagrangian_grid_0.xmf")).getroot()
+    assert next(free.iter("Topology")).get("TopologyType") == "Polyvertex"
+    # a restart against another grid is refused (:497-507)
+    io = MPIIO(mpi_construct=c, real_dtype=real_t)
+    io.define_eulerian_grid(origin=(dx / 2) * np.ones(2), dx=2 * dx * np.ones(2), grid_size=grid_size, ghost_size=g)
+    io.add_as_eulerian_fields_for_io(vorticity=loaded[0])
+    with pytest.raises(AssertionError):
+        io.load(path)
+    io = MPIIO(mpi_construct=c, real_dtype=real_t)
+    io.define_eulerian_grid(origin=(dx / 2) * np.ones(2), dx=dx * np.ones(2), grid_size=grid_size, ghost_size=g)
+    io.add_as_eulerian_fields_for_io(not_in_file=loaded[0])
+    with pytest.raises(AssertionError):
+        io.load(path)
+    with pytest.raises(ValueError):
+        io.add_as_eulerian_fields_for_io(bad_shape=np.zeros((3, 3), dtype=real_t))
+    with pytest.raises(AssertionError):
+        io.add_as_eulerian_fields_for_io(wrong_type=np.zeros(padded, dtype=np.int32))
+
+
+def test_cosserat_rod_io(smi, tmp_path):
+    """mpi_io.py:763-805: element centres and radii of a rod as the connected grid 'rod'."""
+    from sopht_mpi_amd.utils import MPIConstruct3D
+    from sopht_mpi_amd.utils.mpi_io import CosseratRodMPIIO
+
+    class Rod:
+        n_elems = 6
+        position_collection = np.linspace(0.0, 1.0, 21).reshape(3, 7)
+        radius = np.full(6, 0.05)
+
+    c = MPIConstruct3D(8, 8, 8, real_t=np.float64, world=SingleWorld())
+    path = str(tmp_path / "rod.h5")
+    io = CosseratRodMPIIO(mpi_construct=c, cosserat_rod=Rod())
+    Rod.position_collection = Rod.position_collection + 1.0      # save() takes the current positions
+    io.save(path, time=2.0)
+    r = h5lite.Reader(path)
+    centres = 0.5 * (Rod.position_collection[:, 1:] + Rod.position_collection[:, :-1])
+    assert np.array_equal(r["Lagrangian/rod/Grid"][...], centres.T)
+    assert np.array_equal(r["Lagrangian/rod/Scalar/scalar_3d"][...], Rod.radius)
+    assert r["Lagrangian/rod/Connection"].dtype == np.int64 and "Eulerian" not in r
