@@ -554,6 +554,7 @@ constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 struct PGeo {
   int nz, ny, nx, nzl, P, nc, KXL, KXP, KXA, zb_shift;
   int c0;  // first component of this launch (components c0 .. c0 + nc - 1)
+  int colbase;  // column kernels: first spectral column of this launch (its tiles start there)
   int nct, n2, n3;  // column kernels: tiles per row, second and third extent of the launch
   int zg;           // y kernels: consecutive planes one workgroup walks over
 };
@@ -630,8 +631,8 @@ struct TileCfg {
 
 // Tile shape of the z convolution: that of the y kernels unless SMI_FFT_ZCOLS asks for another
 // width (8-column tiles, i.e. two 512-lane workgroups per CU, measured slower at every length).
-template <typename T, int LG>
-using ZCfg = TileCfg<T, LG, false, SMI_FFT_ZCOLS>;
+template <typename T, int LG, int WC = SMI_FFT_ZCOLS>
+using ZCfg = TileCfg<T, LG, false, WC>;
 
 // ------------------------------------------------------------------------- y forward
 // The y kernels walk over G.zg consecutive planes and the G.nc components of one column tile
@@ -653,14 +654,15 @@ struct YWalk {
   }
 };
 
-template <typename T, int LG>
-__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, false>::WPE))
+template <typename T, int LG, int WC = 0>
+__global__ void __launch_bounds__((TileCfg<T, LG, false, WC>::NT), (TileCfg<T, LG, false, WC>::WPE))
     k_fft_y_fwd(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
-  FFT_KERNEL_PROLOGUE(false)
+  using YC_ = TileCfg<T, LG, false, WC>;
+  FFT_KERNEL_PROLOGUE_T(false, YC_)
   int ct, zgroup, k3;
   if (!col_tile<Cfg::PF>(G, ct, zgroup, k3)) return;
   const YWalk W(G, zgroup);
-  const int col = ct * TS + t;
+  const int col = G.colbase + ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
   const unsigned off_in = (unsigned)u * G.KXA + col, off_out = (unsigned)u * kystride + col;
@@ -702,14 +704,15 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
 }
 
 // ------------------------------------------------------------------------- y inverse
-template <typename T, int LG>
-__global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, false>::WPE))
+template <typename T, int LG, int WC = 0>
+__global__ void __launch_bounds__((TileCfg<T, LG, false, WC>::NT), (TileCfg<T, LG, false, WC>::WPE))
     k_fft_y_inv(const Cx<T>* __restrict__ in, Cx<T>* __restrict__ out, PGeo G, const Cx<T>* __restrict__ tw4) {
-  FFT_KERNEL_PROLOGUE(false)
+  using YC_ = TileCfg<T, LG, false, WC>;
+  FFT_KERNEL_PROLOGUE_T(false, YC_)
   int ct, zgroup, k3;
   if (!col_tile<Cfg::PF>(G, ct, zgroup, k3)) return;
   const YWalk W(G, zgroup);
-  const int col = ct * TS + t;
+  const int col = G.colbase + ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
   const unsigned off_in = (unsigned)u * kystride + col, off_out = (unsigned)u * G.KXA + col;
@@ -774,10 +777,10 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false>::NT), (TileCfg<T, LG, f
 // rows of the Green's table (read from HBM once, from cache afterwards).  The next tile's
 // column is requested as soon as the registers of the current one are free (after the odd
 // parity pre-twiddle), so its latency hides behind the second half of the arithmetic.
-template <typename T, int LG>
-__global__ void __launch_bounds__((ZCfg<T, LG>::NT), (ZCfg<T, LG>::WPE))
+template <typename T, int LG, int WC = SMI_FFT_ZCOLS>
+__global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
     k_fft_z_conv(Cx<T>* __restrict__ buf, const T* __restrict__ green, PGeo G, const Cx<T>* __restrict__ tw4) {
-  using ZC_ = ZCfg<T, LG>;
+  using ZC_ = ZCfg<T, LG, WC>;
   FFT_KERNEL_PROLOGUE_T(false, ZC_)
   // The mixed plans add their middle-stage operands to the three register sets of this kernel and
   // do not fit 128 registers with the Green's values of both parities held across tiles and the
@@ -786,7 +789,7 @@ __global__ void __launch_bounds__((ZCfg<T, LG>::NT), (ZCfg<T, LG>::WPE))
   constexpr bool LEAN = !Plan<LG>::POW2;
   int ct, kyc, k;
   if (!col_tile<Cfg::PF>(G, ct, kyc, k)) return;
-  const int col = ct * TS + t;
+  const int col = G.colbase + ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const int ZB = 1 << G.zb_shift;
   const size_t blk = (size_t)(2 * G.ny) * ZB * G.KXP;  // elements per z block of one component
@@ -1119,6 +1122,7 @@ int smi_pruned_create(smi_poisson* p) {
   G.nzl = c->nz;
   G.nc = 3;
   G.c0 = 0;
+  G.colbase = 0;
   G.KXL = (G.nx + 1 + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
   // SMI_FFT_TIGHT_PITCH: the tight exchange pitch on a single rank as well (tests, measurements)
@@ -1169,15 +1173,21 @@ int smi_pruned_greens_download(smi_poisson* p, void* host) {
   return smi_memcpy_d2h(p->ctx, host, p->pruned->green, p->pruned->green_bytes);
 }
 
-template <typename T, int LG>
-static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
-  // which: 0 = y_fwd, 1 = z_conv, 2 = y_inv
-  PGeo G = s->G;
-  G.nc = nc;
-  G.c0 = c0;
+// Narrow tiles for the column that is left over after the 16-column tiles of the y passes (nx + 1 = 32 x 16 + 1
+// spectral columns at 512^3).  A full tile for it transforms fifteen pad columns.  Measured at 512^3 on one GPU:
+// y_inv 2.00 -> 1.91 ms, y_fwd 1.98 -> 1.95 ms.  Only there: the narrow launch touches the same 128-byte lines as the
+// full tile it replaces (one 8-byte column per line), so it saves arithmetic, not traffic - nothing for the z
+// convolution, whose narrow launch took as long as the tile it replaced (122 against 118 us), and nothing across
+// ranks, where the narrow launches (80 - 120 us each whatever the rank count) would cost more than the one tile in
+// five they replace.
+constexpr int kNarrowCols = 4;
+
+template <typename T, int LG, int WC>
+static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int colbase, int ncols) {
+  G.colbase = colbase;
   // one-dimensional grid over (column tile, z or folded ky, component), padded to whole XCD rounds
   auto grid_for = [&](int ts, int pf, int n2, int n3) {
-    G.nct = (G.KXL + ts - 1) / ts;
+    G.nct = (ncols + ts - 1) / ts;
     G.n2 = n2;
     G.n3 = n3;
     const long long tiles = (long long)G.nct * n2 * n3, round = 8 * pf;
@@ -1185,28 +1195,55 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
   };
   if (which == 1) {
     // one workgroup per (column tile, folded ky), looping over mirror rows and components
-    using Cfg = ZCfg<T, LG>;
-    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, G.ny + 1, 1);
-    SMI_CHECK(set_lds((const void*)k_fft_z_conv<T, LG>, Cfg::BYTES));
-    SmiProfScope prof(c, PROF_FFT_Z_CONV, 9.0 * nc * smi_S(c));
-    k_fft_z_conv<T, LG><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G,
-                                                                 (const Cx<T>*)s->tw[2]);
+    if constexpr (WC == SMI_FFT_ZCOLS) {
+      using Cfg = ZCfg<T, LG, WC>;
+      const dim3 grid = grid_for(Cfg::TS, Cfg::PF, G.ny + 1, 1);
+      SMI_CHECK(set_lds((const void*)k_fft_z_conv<T, LG, WC>, Cfg::BYTES));
+      k_fft_z_conv<T, LG, WC><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G,
+                                                                       (const Cx<T>*)s->tw[2]);
+    } else {
+      SMI_REQUIRE(false, "the z convolution has no narrow-tile variant");
+    }
   } else {
-    using Cfg = TileCfg<T, LG, false>;
-    G.zg = nc >= 3 ? 1 : 3;  // three tiles per workgroup
+    using Cfg = TileCfg<T, LG, false, WC>;
+    G.zg = G.nc >= 3 ? 1 : 3;  // three tiles per workgroup
     const dim3 grid = grid_for(Cfg::TS, Cfg::PF, (G.nz + G.zg - 1) / G.zg, 1);
     const Cx<T>* tw = (const Cx<T>*)s->tw[1];
     if (which == 0) {
-      SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG>, Cfg::BYTES));
-      SmiProfScope prof(c, PROF_FFT_Y_FWD, 6.0 * nc * smi_S(c));
-      k_fft_y_fwd<T, LG><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, tw);
+      SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG, WC>, Cfg::BYTES));
+      k_fft_y_fwd<T, LG, WC><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((const Cx<T>*)s->bufT, (Cx<T>*)s->bufB, G, tw);
     } else {
-      SMI_CHECK(set_lds((const void*)k_fft_y_inv<T, LG>, Cfg::BYTES));
-      SmiProfScope prof(c, PROF_FFT_Y_INV, 6.0 * nc * smi_S(c));
-      k_fft_y_inv<T, LG><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, tw);
+      SMI_CHECK(set_lds((const void*)k_fft_y_inv<T, LG, WC>, Cfg::BYTES));
+      k_fft_y_inv<T, LG, WC><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((const Cx<T>*)s->bufB, (Cx<T>*)s->bufT, G, tw);
     }
   }
   SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int LG>
+static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
+  // which: 0 = y_fwd, 1 = z_conv, 2 = y_inv
+  PGeo G = s->G;
+  G.nc = nc;
+  G.c0 = c0;
+  constexpr int kMainZ = SMI_FFT_ZCOLS;
+  const int ts_main = which == 1 ? ZCfg<T, LG, kMainZ>::TS : TileCfg<T, LG, false, 0>::TS;
+  constexpr int ts_narrow = TileCfg<T, LG, false, kNarrowCols>::TS;
+  const int rest = G.KXL % ts_main;
+  static const bool no_narrow = getenv("SMI_FFT_NO_NARROW_TILES") != nullptr;
+  const bool split = !no_narrow && which != 1 && G.P == 1 && ts_narrow < ts_main && rest > 0 && rest <= ts_narrow &&
+                     G.KXL > ts_main;
+  const int slot = which == 0 ? PROF_FFT_Y_FWD : (which == 1 ? PROF_FFT_Z_CONV : PROF_FFT_Y_INV);
+  SmiProfScope prof(c, slot, (which == 1 ? 9.0 : 6.0) * nc * smi_S(c));
+  const int main_cols = split ? G.KXL - rest : G.KXL;
+  if (which == 1)
+    SMI_CHECK((launch_cols_tiles<T, LG, kMainZ>(c, s, which, G, 0, main_cols)));
+  else
+    SMI_CHECK((launch_cols_tiles<T, LG, 0>(c, s, which, G, 0, main_cols)));
+  if constexpr (kMainZ != kNarrowCols) {
+    if (split && which != 1) SMI_CHECK((launch_cols_tiles<T, LG, kNarrowCols>(c, s, which, G, main_cols, rest)));
+  }
   return 0;
 }
 
