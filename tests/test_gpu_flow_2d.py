@@ -1,5 +1,6 @@
 """GPU parity of the 2D path: operators and whole steps of UnboundedFlowSimulator2D against the
-oracle's 2D restatement, and the reference's Lamb-Oseen case on the GPU."""
+oracle's 2D restatement.  (The reference's Lamb-Oseen case runs in test_analytic_pins.py, the 2D path over several
+ranks in test_gpu_slabs.py.)"""
 import ctypes as C
 
 import numpy as np
