@@ -118,19 +118,23 @@ __global__ void __launch_bounds__(kB) k2_sum(T* __restrict__ out, const T* __res
   if (i < n) out[i] = a[i] + b[i];
 }
 
-// u = p d(psi)/dy, v = -p d(psi)/dx on D, 0 elsewhere (outplane_field_curl_mpi_2d.py)
-template <typename T>
-__global__ void __launch_bounds__(kB) k2_outplane_curl(T* __restrict__ curl, const T* __restrict__ f, T p, G2 G) {
+// u = p d(psi)/dy, v = -p d(psi)/dx on D, 0 elsewhere (outplane_field_curl_mpi_2d.py); ADD: plus a constant per
+// component on every cell (the free stream of flow_simulators_mpi_2d.py:222-233, added in the store instead of in a
+// second pass over the velocity)
+template <typename T, bool ADD = false>
+__global__ void __launch_bounds__(kB) k2_outplane_curl(T* __restrict__ curl, const T* __restrict__ f, T p, G2 G,
+                                                      T add_u = T(0), T add_v = T(0)) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.n) return;
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   T u = T(0), v = T(0);
-  if (core_y(G, y, 1) && core_s(x, G.px, G.g, 1)) {
+  const bool in_d = core_y(G, y, 1) && core_s(x, G.px, G.g, 1);
+  if (in_d) {
     u = p * (f[i + G.px] - f[i - G.px]);
     v = -p * (f[i + 1] - f[i - 1]);
   }
-  curl[i] = u;
-  curl[G.n + i] = v;
+  curl[i] = ADD ? (in_d ? u : T(0)) + add_u : u;
+  curl[G.n + i] = ADD ? (in_d ? v : T(0)) + add_v : v;
 }
 
 // w += p (d f_y / dx - d f_x / dy) on U_1 (update_vorticity_from_velocity_forcing_mpi_2d.py)
@@ -168,20 +172,26 @@ __global__ void __launch_bounds__(kB) k2_penalise(T* __restrict__ f, G2 G, int w
   }
 }
 
+// out = in + val (add) or val, over ncomp components of n cells each with one constant per component (at most 2)
 template <typename T>
-__global__ void __launch_bounds__(kB) k2_set_add(T* __restrict__ out, const T* __restrict__ in, T val, long long n,
-                                                int add) {
+__global__ void __launch_bounds__(kB) k2_set_add(T* __restrict__ out, const T* __restrict__ in, T val0, T val1,
+                                                long long n, long long total, int add) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = add ? in[i] + val : val;
+  if (i >= total) return;
+  const T val = i < n ? val0 : val1;
+  out[i] = add ? in[i] + val : val;
 }
 
-// One-block reductions over the interior.  MODE 0: max of |u| + |v|; MODE 1: max of f.
+// Reductions over the interior in two launches: up to kRed2Blocks partial maxima, then one block over those.
+// MODE 0: max of |u| + |v|; MODE 1: max of f.
+constexpr int kRed2Blocks = 128;
 template <typename T, int MODE>
-__global__ void __launch_bounds__(1024) k2_reduce_max(const T* __restrict__ f, G2 G, double* __restrict__ out) {
-  __shared__ double part[1024];
+__global__ void __launch_bounds__(256) k2_reduce_partial(const T* __restrict__ f, G2 G, double* __restrict__ partials) {
+  __shared__ double part[256];
   const int ny = G.py - 2 * G.g, nx = G.px - 2 * G.g;
+  const long long cells = (long long)ny * nx;
   double m = -1.0e300;
-  for (long long k = threadIdx.x; k < (long long)ny * nx; k += blockDim.x) {
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < cells; k += (long long)gridDim.x * blockDim.x) {
     const int y = (int)(k / nx) + G.g, x = (int)(k % nx) + G.g;
     const long long i = (long long)y * G.px + x;
     const T v = MODE == 0 ? (T)(fabs(f[i]) + fabs(f[G.n + i])) : f[i];
@@ -190,6 +200,17 @@ __global__ void __launch_bounds__(1024) k2_reduce_max(const T* __restrict__ f, G
   part[threadIdx.x] = m;
   __syncthreads();
   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) part[threadIdx.x] = fmax(part[threadIdx.x], part[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(kRed2Blocks) k2_reduce_final(const double* __restrict__ partials, int n,
+                                                              double* __restrict__ out) {
+  __shared__ double part[kRed2Blocks];
+  part[threadIdx.x] = (int)threadIdx.x < n ? partials[threadIdx.x] : -1.0e300;
+  __syncthreads();
+  for (int s = kRed2Blocks / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) part[threadIdx.x] = fmax(part[threadIdx.x], part[threadIdx.x + s]);
     __syncthreads();
   }
@@ -458,9 +479,11 @@ extern "C" int smi2d_penalise_boundary(smi_ctx* c, void* field, int width, const
 
 static int set_add2(smi_ctx* c, void* out, const void* in, int ncomp, const double* vals, int add) {
   G2 G = geo2(c);
+  SMI_REQUIRE(ncomp <= 2, "2D fields have one or two components (got %d)", ncomp);
+  const long long total = (long long)ncomp * G.n;
   SMI_DISPATCH(c, {
-    for (int k = 0; k < ncomp; ++k)
-      k2_set_add<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)out + k * G.n, (const T*)in + k * G.n, (T)vals[k], G.n, add);
+    k2_set_add<T><<<nblocks(total), kB, 0, c->stream>>>((T*)out, (const T*)in, (T)vals[0], (T)vals[ncomp - 1], G.n, total,
+                                                       add);
   });
   SMI_LAUNCH_CHECK();
   return 0;
@@ -481,9 +504,13 @@ extern "C" int smi2d_add_fixed_val(smi_ctx* c, void* sum_field, const void* fiel
 template <int MODE>
 static int reduce2(smi_ctx* c, const void* f, double* out) {
   G2 G = geo2(c);
-  SMI_DISPATCH(c, { k2_reduce_max<T, MODE><<<1, 1024, 0, c->stream>>>((const T*)f, G, (double*)c->red_partials); });
+  double* partials = (double*)c->red_partials;
+  const long long cells = (long long)c->ny * c->nx;
+  const int blocks = (int)((cells + 1023) / 1024 < kRed2Blocks ? (cells + 1023) / 1024 : kRed2Blocks);
+  SMI_DISPATCH(c, { k2_reduce_partial<T, MODE><<<blocks, 256, 0, c->stream>>>((const T*)f, G, partials); });
+  k2_reduce_final<<<1, kRed2Blocks, 0, c->stream>>>(partials, blocks, partials + kRed2Blocks);
   SMI_LAUNCH_CHECK();
-  SMI_CHECK_HIP(hipMemcpyAsync(c->red_host, c->red_partials, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  SMI_CHECK_HIP(hipMemcpyAsync(c->red_host, partials + kRed2Blocks, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
   *out = c->red_host[0];
   return 0;
@@ -816,8 +843,17 @@ extern "C" int smi2d_flow_step_ns(smi_ctx* c, smi_poisson2d* p, void* vorticity,
   SMI_CHECK(smi2d_diffusion_timestep(c, vorticity, buffer_scalar, r(nu * dt / dx / dx)));
   if (penalty_width > 0) SMI_CHECK(smi2d_penalise_boundary(c, vorticity, penalty_width, fac_lo, fac_hi));
   SMI_CHECK(smi2d_poisson_solve(p, stream_func, vorticity));
-  SMI_CHECK(smi2d_outplane_field_curl(c, velocity, stream_func, r(0.5 / dx)));
-  if (free_stream) SMI_CHECK(smi2d_add_fixed_val(c, velocity, velocity, 2, free_stream));
+  if (free_stream) {
+    SMI_CHECK(halo2(c, stream_func, 1));
+    G2 G = geo2(c);
+    SMI_DISPATCH(c, {
+      k2_outplane_curl<T, true><<<nblocks(G.n), kB, 0, c->stream>>>((T*)velocity, (const T*)stream_func, (T)r(0.5 / dx), G,
+                                                                    (T)free_stream[0], (T)free_stream[1]);
+    });
+    SMI_LAUNCH_CHECK();
+  } else {
+    SMI_CHECK(smi2d_outplane_field_curl(c, velocity, stream_func, r(0.5 / dx)));
+  }
   if (forcing) {
     const double z2[2] = {0.0, 0.0};
     SMI_CHECK(smi2d_set_fixed_val(c, forcing, 2, z2));
