@@ -20,6 +20,7 @@
 #include <hipfft/hipfft.h>
 
 #include "smi_common.h"
+#include "smi_prof.h"
 
 #define SMI_CHECK_FFT2(expr)                                                              \
   do {                                                                                    \
@@ -38,6 +39,16 @@ struct smi_poisson2d {
   void* gather_send;  // several ranks: this rank's interior rows, one copy per peer for the host-staged transport
   void* gather_recv;  // several ranks: the interior of the whole plane, (ny, nx)
   hipfftHandle fwd, inv;
+  // The captured step of smi2d_flow_step_ns (single rank): executable graph, what it was captured for, and the
+  // device array its kernels read the per-step coefficients from
+  hipGraph_t step_graph;
+  hipGraphExec_t step_exec;
+  int step_state;          // 0: not captured, 1: ready, -1: capture failed once, eager from then on
+  int eager_steps;         // steps run launch by launch so far (the first ones always are: lazy set-up of the plans)
+  const void* step_key[5];
+  int step_width, step_has_fs;
+  double step_fac[2][32];
+  double* step_coef;
   void* real_buf;   // (2ny, 2nx) reals
   void* cplx_buf;   // (2ny, nx + 1) complex
   void* ghat;       // (2ny, nx + 1) complex, times dx^2 / (4 ny nx)
@@ -70,11 +81,25 @@ __device__ __forceinline__ bool in_update_set(int y, int x, const G2& G, int s) 
          (ext_s(y, G.py, s) && face_s(x, G.px, G.g, s));
 }
 
+// A coefficient of a step: a value, or - in the replays of a captured step, whose kernel arguments are frozen - a
+// slot of a small device array that the host refreshes before every replay (the time step changes from step to step).
+template <typename T>
+struct Coef {
+  T value;
+  const double* slot;
+  __device__ __forceinline__ T get() const { return slot ? (T)*slot : value; }
+};
+template <typename T>
+Coef<T> coef_of(double v) {
+  return Coef<T>{(T)v, nullptr};
+}
+
 // flux = c (f(x+1) + f(x-1) + f(y+1) + f(y-1) - 4 f) on D, 0 elsewhere; ADD: out = f + flux
 template <typename T, bool ADD>
-__global__ void __launch_bounds__(kB) k2_diffusion(T* __restrict__ out, const T* __restrict__ f, T c, G2 G) {
+__global__ void __launch_bounds__(kB) k2_diffusion(T* __restrict__ out, const T* __restrict__ f, Coef<T> cc, G2 G) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.n) return;
+  const T c = cc.get();
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   T v = T(0);
   if (core_y(G, y, 1) && core_s(x, G.px, G.g, 1))
@@ -94,9 +119,10 @@ __device__ __forceinline__ T upwind3_face2(const T* f, const T* v, long long str
 // KEEP: cells outside U_2 keep their value (the stand-alone flux operator)
 template <typename T, bool KEEP = false>
 __global__ void __launch_bounds__(kB) k2_advection_flux(T* __restrict__ flux, const T* __restrict__ f,
-                                                       const T* __restrict__ vel, T c, G2 G) {
+                                                       const T* __restrict__ vel, Coef<T> cc, G2 G) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.n) return;
+  const T c = cc.get();
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   T val = T(0);
   const bool in_u = in_update_set(y, x, G, 2);
@@ -122,10 +148,12 @@ __global__ void __launch_bounds__(kB) k2_sum(T* __restrict__ out, const T* __res
 // component on every cell (the free stream of flow_simulators_mpi_2d.py:222-233, added in the store instead of in a
 // second pass over the velocity)
 template <typename T, bool ADD = false>
-__global__ void __launch_bounds__(kB) k2_outplane_curl(T* __restrict__ curl, const T* __restrict__ f, T p, G2 G,
-                                                      T add_u = T(0), T add_v = T(0)) {
+__global__ void __launch_bounds__(kB) k2_outplane_curl(T* __restrict__ curl, const T* __restrict__ f, Coef<T> pc, G2 G,
+                                                      Coef<T> au = Coef<T>{T(0), nullptr},
+                                                      Coef<T> av = Coef<T>{T(0), nullptr}) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.n) return;
+  const T p = pc.get(), add_u = au.get(), add_v = av.get();
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   T u = T(0), v = T(0);
   const bool in_d = core_y(G, y, 1) && core_s(x, G.px, G.g, 1);
@@ -139,9 +167,10 @@ __global__ void __launch_bounds__(kB) k2_outplane_curl(T* __restrict__ curl, con
 
 // w += p (d f_y / dx - d f_x / dy) on U_1 (update_vorticity_from_velocity_forcing_mpi_2d.py)
 template <typename T>
-__global__ void __launch_bounds__(kB) k2_update_vorticity(T* __restrict__ w, const T* __restrict__ f, T p, G2 G) {
+__global__ void __launch_bounds__(kB) k2_update_vorticity(T* __restrict__ w, const T* __restrict__ f, Coef<T> pc, G2 G) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.n) return;
+  const T p = pc.get();
   const int y = (int)(i / G.px), x = (int)(i - (long long)y * G.px);
   if (!in_update_set(y, x, G, 1)) return;
   const T* fx = f + i;
@@ -382,7 +411,7 @@ extern "C" int smi2d_diffusion_flux(smi_ctx* c, void* flux, const void* field, d
   SMI_REQUIRE(flux && field && flux != field, "smi2d_diffusion_flux: bad argument");
   SMI_CHECK(halo2(c, (void*)field, 1));
   G2 G = geo2(c);
-  SMI_DISPATCH(c, { k2_diffusion<T, false><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (T)prefactor, G); });
+  SMI_DISPATCH(c, { k2_diffusion<T, false><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, coef_of<T>(prefactor), G); });
   SMI_LAUNCH_CHECK();
   return 0;
 }
@@ -405,7 +434,7 @@ extern "C" int smi2d_advection_timestep_eno3(smi_ctx* c, void* field, void* flux
   G2 G = geo2(c);
   SMI_DISPATCH(c, {
     k2_advection_flux<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (const T*)velocity,
-                                                            (T)(-dt_by_dx), G);
+                                                            coef_of<T>(-dt_by_dx), G);
     k2_sum<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)field, (const T*)field, (const T*)flux, G.n);
   });
   SMI_LAUNCH_CHECK();
@@ -423,7 +452,7 @@ extern "C" int smi2d_advection_flux_eno3(smi_ctx* c, void* flux, const void* fie
   G2 G = geo2(c);
   SMI_DISPATCH(c, {
     k2_advection_flux<T, true><<<nblocks(G.n), kB, 0, c->stream>>>((T*)flux, (const T*)field, (const T*)velocity,
-                                                                  (T)inv_dx, G);
+                                                                  coef_of<T>(inv_dx), G);
   });
   SMI_LAUNCH_CHECK();
   return 0;
@@ -434,7 +463,7 @@ extern "C" int smi2d_outplane_field_curl(smi_ctx* c, void* curl, const void* fie
   SMI_REQUIRE(curl && field && curl != field, "smi2d_outplane_field_curl: bad argument");
   SMI_CHECK(halo2(c, (void*)field, 1));
   G2 G = geo2(c);
-  SMI_DISPATCH(c, { k2_outplane_curl<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)curl, (const T*)field, (T)prefactor, G); });
+  SMI_DISPATCH(c, { k2_outplane_curl<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)curl, (const T*)field, coef_of<T>(prefactor), G); });
   SMI_LAUNCH_CHECK();
   return 0;
 }
@@ -446,7 +475,7 @@ extern "C" int smi2d_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vo
   SMI_CHECK(halo2(c, (void*)forcing, 2));
   G2 G = geo2(c);
   SMI_DISPATCH(c, {
-    k2_update_vorticity<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)vorticity, (const T*)forcing, (T)prefactor, G);
+    k2_update_vorticity<T><<<nblocks(G.n), kB, 0, c->stream>>>((T*)vorticity, (const T*)forcing, coef_of<T>(prefactor), G);
   });
   SMI_LAUNCH_CHECK();
   return 0;
@@ -577,6 +606,9 @@ extern "C" int smi2d_poisson_destroy(smi_poisson2d* p) {
   hipFree(p->ghat);
   if (p->gather_send) hipFree(p->gather_send);
   if (p->gather_recv) hipFree(p->gather_recv);
+  if (p->step_exec) hipGraphExecDestroy(p->step_exec);
+  if (p->step_graph) hipGraphDestroy(p->step_graph);
+  if (p->step_coef) hipFree(p->step_coef);
   delete p;
   return 0;
 }
@@ -830,33 +862,132 @@ extern "C" int smi2d_halo_exchange(smi_ctx* c, void* field, int ncomp) {
 
 // One 2D Navier-Stokes step sequenced inside the library (flow_simulators_mpi_2d.py:260-298): the
 // forcing update, ENO3 advection, diffusion, penalisation, Poisson solve, curl and free stream,
-// one host call instead of seven: the 256^2 step is bound by launch and call overhead.
+// one host call instead of seven.  The 256^2 step is bound by launch overhead (some fifteen kernels of a few
+// microseconds each), so on a single rank the sequence is captured into a HIP graph once and replayed: the arrays
+// and the penalisation tables are the same every step, and what changes with the time step - four prefactors and the
+// free stream - is read by the kernels from a small device array that a one-lane kernel refreshes before each
+// replay.  SMI_2D_NO_GRAPH=1 keeps the launch-by-launch path.
+namespace {
+enum { CF_FORCING, CF_ADVECT, CF_DIFFUSE, CF_CURL, CF_FS_U, CF_FS_V, CF_COUNT };
+struct CoefVals {
+  double v[CF_COUNT];
+};
+__global__ void k2_write_coefs(double* __restrict__ dst, CoefVals vals) {
+  if (threadIdx.x < CF_COUNT) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
+// the launches of one step; dev != nullptr: coefficients come from that device array (capture / replay)
+template <typename T>
+int step2_launches(smi_ctx* c, smi_poisson2d* p, T* w, T* vel, T* psi, T* buf, T* forcing, const CoefVals& val,
+                   const double* dev, int penalty_width, const double* fac_lo, const double* fac_hi, bool has_fs) {
+  auto cf = [&](int i) { return Coef<T>{(T)val.v[i], dev ? dev + i : nullptr}; };
+  const G2 G = geo2(c);
+  const int nb = nblocks(G.n);
+  if (forcing) {
+    SMI_CHECK(halo2(c, forcing, 2));
+    k2_update_vorticity<T><<<nb, kB, 0, c->stream>>>(w, forcing, cf(CF_FORCING), G);
+  }
+  SMI_CHECK(halo2(c, w, 1));
+  SMI_CHECK(halo2(c, vel, 2));
+  k2_advection_flux<T><<<nb, kB, 0, c->stream>>>(buf, w, vel, cf(CF_ADVECT), G);
+  k2_sum<T><<<nb, kB, 0, c->stream>>>(w, w, buf, G.n);
+  SMI_CHECK(halo2(c, w, 1));
+  k2_diffusion<T, false><<<nb, kB, 0, c->stream>>>(buf, w, cf(CF_DIFFUSE), G);
+  k2_sum<T><<<nb, kB, 0, c->stream>>>(w, w, buf, G.n);
+  SMI_LAUNCH_CHECK();
+  if (penalty_width > 0) SMI_CHECK(smi2d_penalise_boundary(c, w, penalty_width, fac_lo, fac_hi));
+  SMI_CHECK(smi2d_poisson_solve(p, psi, w));
+  SMI_CHECK(halo2(c, psi, 1));
+  if (has_fs)
+    k2_outplane_curl<T, true><<<nb, kB, 0, c->stream>>>(vel, psi, cf(CF_CURL), G, cf(CF_FS_U), cf(CF_FS_V));
+  else
+    k2_outplane_curl<T, false><<<nb, kB, 0, c->stream>>>(vel, psi, cf(CF_CURL), G);
+  SMI_LAUNCH_CHECK();
+  if (forcing) {
+    const double z2[2] = {0.0, 0.0};
+    SMI_CHECK(set_add2(c, forcing, forcing, 2, z2, 0));
+  }
+  return 0;
+}
+
+void drop_step_graph(smi_poisson2d* p) {
+  if (p->step_exec) hipGraphExecDestroy(p->step_exec);
+  if (p->step_graph) hipGraphDestroy(p->step_graph);
+  p->step_exec = nullptr;
+  p->step_graph = nullptr;
+  if (p->step_state > 0) p->step_state = 0;
+}
+}  // namespace
+
 extern "C" int smi2d_flow_step_ns(smi_ctx* c, smi_poisson2d* p, void* vorticity, void* velocity, void* stream_func,
                                   void* buffer_scalar, void* forcing, double dt, double nu, double dx,
                                   int penalty_width, const double* fac_lo, const double* fac_hi,
                                   const double* free_stream) {
   SMI_REQUIRE(c && p && vorticity && velocity && stream_func && buffer_scalar, "smi2d_flow_step_ns: null argument");
+  SMI_REQUIRE(p->ctx == c, "smi2d_flow_step_ns: the Poisson solver belongs to another context");
+  SMI_REQUIRE(c->g >= 2, "smi2d_flow_step_ns: the advection stencil needs ghost_size >= 2 (got %d)", c->g);
+  SMI_REQUIRE(penalty_width == 0 || (fac_lo && fac_hi), "smi2d_flow_step_ns: penalisation tables missing");
+  SMI_REQUIRE(penalty_width >= 0 && c->g + penalty_width <= 16, "smi2d_flow_step_ns: bad penalty zone width %d",
+              penalty_width);
   // prefactors rounded to the real type exactly as the reference does with real_t(...)
   auto r = [&](double v) { return c->dtype == SMI_F32 ? (double)(float)v : v; };
-  if (forcing) SMI_CHECK(smi2d_update_vorticity_from_velocity_forcing(c, vorticity, forcing, r(dt / (2 * dx))));
-  SMI_CHECK(smi2d_advection_timestep_eno3(c, vorticity, buffer_scalar, velocity, r(dt / dx)));
-  SMI_CHECK(smi2d_diffusion_timestep(c, vorticity, buffer_scalar, r(nu * dt / dx / dx)));
-  if (penalty_width > 0) SMI_CHECK(smi2d_penalise_boundary(c, vorticity, penalty_width, fac_lo, fac_hi));
-  SMI_CHECK(smi2d_poisson_solve(p, stream_func, vorticity));
-  if (free_stream) {
-    SMI_CHECK(halo2(c, stream_func, 1));
-    G2 G = geo2(c);
+  CoefVals val;
+  val.v[CF_FORCING] = r(dt / (2 * dx));
+  val.v[CF_ADVECT] = -r(dt / dx);
+  val.v[CF_DIFFUSE] = r(nu * dt / dx / dx);
+  val.v[CF_CURL] = r(0.5 / dx);
+  val.v[CF_FS_U] = free_stream ? r(free_stream[0]) : 0.0;
+  val.v[CF_FS_V] = free_stream ? r(free_stream[1]) : 0.0;
+  const bool has_fs = free_stream != nullptr;
+  const int nfac = 2 * (c->g + penalty_width);  // entries of each table: x band, then y band
+  auto eager = [&]() -> int {
+    ++p->eager_steps;
     SMI_DISPATCH(c, {
-      k2_outplane_curl<T, true><<<nblocks(G.n), kB, 0, c->stream>>>((T*)velocity, (const T*)stream_func, (T)r(0.5 / dx), G,
-                                                                    (T)free_stream[0], (T)free_stream[1]);
+      return step2_launches<T>(c, p, (T*)vorticity, (T*)velocity, (T*)stream_func, (T*)buffer_scalar, (T*)forcing, val,
+                               nullptr, penalty_width, fac_lo, fac_hi, has_fs);
     });
-    SMI_LAUNCH_CHECK();
-  } else {
-    SMI_CHECK(smi2d_outplane_field_curl(c, velocity, stream_func, r(0.5 / dx)));
+    return 0;
+  };
+  static const bool no_graph = getenv("SMI_2D_NO_GRAPH") != nullptr;
+  const bool profiling = c->prof && c->prof->on;
+  if (no_graph || c->nranks > 1 || profiling || p->step_state < 0 || p->eager_steps < 2) return eager();
+
+  const void* key[5] = {vorticity, velocity, stream_func, buffer_scalar, forcing};
+  bool same = p->step_state == 1 && memcmp(key, p->step_key, sizeof(key)) == 0 && p->step_width == penalty_width &&
+              p->step_has_fs == (int)has_fs;
+  if (same && penalty_width > 0)
+    same = memcmp(p->step_fac[0], fac_lo, nfac * sizeof(double)) == 0 &&
+           memcmp(p->step_fac[1], fac_hi, nfac * sizeof(double)) == 0;
+  if (!same) {
+    drop_step_graph(p);
+    if (!p->step_coef) SMI_CHECK_HIP(hipMalloc((void**)&p->step_coef, sizeof(double) * 8));
+    SMI_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    SMI_DISPATCH(c, {
+      rc = step2_launches<T>(c, p, (T*)vorticity, (T*)velocity, (T*)stream_func, (T*)buffer_scalar, (T*)forcing, val,
+                             p->step_coef, penalty_width, fac_lo, fac_hi, has_fs);
+    });
+    hipError_t e = hipStreamEndCapture(c->stream, &p->step_graph);  // always: leaves capture mode
+    if (rc == 0 && e == hipSuccess) e = hipGraphInstantiate(&p->step_exec, p->step_graph, nullptr, nullptr, 0);
+    if (rc != 0 || e != hipSuccess) {
+      fprintf(stderr, "libsophtmi: capturing the 2D step failed (%s); steps run launch by launch\n",
+              rc ? smi_last_error() : hipGetErrorString(e));
+      (void)hipGetLastError();
+      drop_step_graph(p);
+      p->step_state = -1;
+      return eager();
+    }
+    memcpy(p->step_key, key, sizeof(key));
+    p->step_width = penalty_width;
+    p->step_has_fs = has_fs;
+    if (penalty_width > 0) {
+      memcpy(p->step_fac[0], fac_lo, nfac * sizeof(double));
+      memcpy(p->step_fac[1], fac_hi, nfac * sizeof(double));
+    }
+    p->step_state = 1;
   }
-  if (forcing) {
-    const double z2[2] = {0.0, 0.0};
-    SMI_CHECK(smi2d_set_fixed_val(c, forcing, 2, z2));
-  }
+  k2_write_coefs<<<1, 64, 0, c->stream>>>(p->step_coef, val);
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK_HIP(hipGraphLaunch(p->step_exec, c->stream));
   return 0;
 }
