@@ -40,11 +40,20 @@ def main():
             d[r["kernel"]][r["counter"]] = float(r["avg_per_dispatch"])
     kernels = {}
     for slot, prefix in SLOTS.items():
-        name = next((k for k in d if k.startswith(prefix)), None)
-        if name is None:
+        names = [k for k in d if k.startswith(prefix)]
+        if not names:
             continue
-        c = d[name]
-        rec = {"kernel": name}
+        # a slot may cover several launches (the y passes: 16-column tiles, then narrow tiles for the column left
+        # over): additive counters are summed over them, the wave-time split is that of the longest launch
+        names.sort(key=lambda k: -d[k].get("SQ_WAVE_CYCLES", d[k].get("FETCH_SIZE", 0.0)))
+        c = dict(d[names[0]])
+        for extra in names[1:]:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+                if counter in c and counter in d[extra]:
+                    c[counter] += d[extra][counter]
+        rec = {"kernel": names[0]}
+        if len(names) > 1:
+            rec["also"] = names[1:]
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             rec["fetch_size_kib_raw"] = c["FETCH_SIZE"]
             rec["write_size_kib"] = c["WRITE_SIZE"]
