@@ -81,6 +81,7 @@ class UnboundedFlowSimulatorBase:
         self._build_operators(dict(mpi_construct=self.mpi_construct, real_t=self.real_t,
                                    ghost_exchange_communicator=self.mpi_ghost_exchange_communicator))
         self._step_stages = self._stages()
+        self._publish_steps()
 
     def _derive_geometry(self):
         """Grid spacing, axis ranges and the host ``position_field`` (component 0 = x) of this rank's block."""
@@ -115,10 +116,28 @@ class UnboundedFlowSimulatorBase:
         self.time += dt
 
     def time_step(self, dt, **kwargs):
-        """One flow step: the stages of this flow type in order, then the clock."""
-        for stage in self._step_stages:
-            stage(dt=dt, **kwargs)
+        """One flow step (``flow_time_step``: the stages of this flow type in order), then the clock."""
+        self.flow_time_step(dt=dt, **kwargs)
         self.update_simulator_time(dt=dt)
+
+    @staticmethod
+    def _in_sequence(stages):
+        def step(dt, **kwargs):
+            for stage in stages:
+                stage(dt=dt, **kwargs)
+        return step
+
+    def _publish_steps(self):
+        """The callables users of the reference reach for besides ``time_step``: ``flow_time_step`` (what
+        ``time_step`` runs; the reference picks it in ``finalise_flow_timestep``, flow_simulators_mpi_3d.py:335-345,
+        _2d.py:242-249) and the step of each flow family under the reference's method name
+        (``navier_stokes_with_forcing_timestep`` ...), each a stage list of this simulator run in order."""
+        self.flow_time_step = self._in_sequence(self._step_stages)
+        for name, stages in self._named_stage_lists().items():
+            setattr(self, name, self._in_sequence(stages))
+
+    def _named_stage_lists(self):
+        return {}
 
     def _scaled(self, value):
         """A step coefficient rounded to the field precision, as the reference passes real_t(...)."""

@@ -99,6 +99,19 @@ class UnboundedFlowSimulator2D(UnboundedFlowSimulatorBase):
                                                          fixed_vals=[0.0] * self.grid_dim))
         return stages
 
+    def _named_stage_lists(self):
+        """flow_simulators_mpi_2d.py:260-298 by name."""
+        transport = [self._advect, self._diffuse]
+        names = {"advection_and_diffusion_timestep": transport}
+        if self.solves_vorticity:
+            plain = self._step_stages if not self.has_forcing else transport + [
+                lambda dt, **_: self.compute_velocity_from_vorticity(),
+                lambda dt, free_stream_velocity=(0.0, 0.0): self.update_velocity_with_free_stream(free_stream_velocity)]
+            names["navier_stokes_timestep"] = plain
+        if self.has_forcing:
+            names["navier_stokes_with_forcing_timestep"] = self._step_stages
+        return names
+
     def _apply_forcing(self, dt, **_):
         self.update_vorticity_from_velocity_forcing(
             vorticity_field=self.vorticity_field, velocity_forcing_field=self.eul_grid_forcing_field,

@@ -143,6 +143,24 @@ class UnboundedFlowSimulator3D(UnboundedFlowSimulatorBase):
                                                          fixed_vals=[0.0] * self.grid_dim))
         return stages
 
+    def _named_stage_lists(self):
+        """flow_simulators_mpi_3d.py:356-424 by name.  The plain Navier-Stokes step of a simulator with forcing is
+        the operator sequence without the forcing update and reset (the one-call step always includes them)."""
+        if not self.solves_vorticity:
+            name = "scalar" if self.flow_type == "passive_scalar" else "vector"
+            return {f"{name}_advection_and_diffusion_timestep": self._step_stages}
+        if not self.has_forcing:
+            plain = self._step_stages
+        else:
+            plain = [self._advect_vorticity_rotational_form, self._diffuse_vorticity]
+            if self.filter_setting_dict is not None:
+                plain.append(lambda dt, **_: self.filter_vector_field(vector_field=self.vorticity_field))
+            plain.append(lambda dt, free_stream_velocity=None: self.compute_flow_velocity(free_stream_velocity))
+        names = {"rotational_form_navier_stokes_timestep": plain, "navier_stokes_timestep": plain}
+        if self.has_forcing:
+            names["navier_stokes_with_forcing_timestep"] = self._step_stages
+        return names
+
     def _primary(self):
         if self.flow_type == "passive_scalar":
             return {"field": self.primary_scalar_field}

@@ -156,3 +156,49 @@ def test_invalid_arguments(smi):
         UnboundedFlowSimulator3D(grid_size=(8, 8, 8), x_range=1.0, kinematic_viscosity=1.0, flow_type="bogus")
     with pytest.raises(ValueError):  # ghost size smaller than the ENO3 support
         UnboundedFlowSimulator3D(grid_size=(8, 8, 8), x_range=1.0, kinematic_viscosity=1.0, ghost_size=1)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_named_step_callables(smi, dim):
+    """The reference exposes each flow family's step under its own name next to ``time_step``
+    (flow_simulators_mpi_3d.py:335-424, _2d.py:242-298): here they run the same stage lists."""
+    from sopht_mpi_amd.simulator import UnboundedFlowSimulator2D, UnboundedFlowSimulator3D
+
+    real_t = np.float32
+    n = (16, 24, 32)[-dim:]
+    cls = UnboundedFlowSimulator3D if dim == 3 else UnboundedFlowSimulator2D
+    kw = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, real_t=real_t, with_free_stream_flow=True)
+    rng = np.random.default_rng(12)
+    fs = np.array([1.0, -0.5, 0.25])[:dim]
+    forced = [cls(flow_type="navier_stokes_with_forcing", **kw) for _ in range(3)]
+    plain = cls(flow_type="navier_stokes", fused_step=False, **kw)
+    shape = forced[0].vorticity_field.shape
+    w0 = (rng.random(shape) - 0.5).astype(real_t)
+    f0 = (rng.random(forced[0].eul_grid_forcing_field.shape) - 0.5).astype(real_t) * real_t(0.1)
+    for sim in forced + [plain]:
+        sim.vorticity_field[...] = w0
+        if dim == 3:
+            sim.compute_flow_velocity(free_stream_velocity=fs)
+        else:
+            sim.compute_velocity_from_vorticity()
+            sim.update_velocity_with_free_stream(fs)
+    for sim in forced:
+        sim.eul_grid_forcing_field[...] = f0
+    dt = 0.5 * forced[0].compute_stable_timestep()
+    forced[0].time_step(dt=dt, free_stream_velocity=fs)
+    forced[1].navier_stokes_with_forcing_timestep(dt=dt, free_stream_velocity=fs)
+    assert forced[0].time == dt and forced[1].time == 0.0          # only time_step moves the clock
+    assert np.array_equal(forced[0].vorticity_field.get(), forced[1].vorticity_field.get())
+    assert np.array_equal(forced[0].velocity_field.get(), forced[1].velocity_field.get())
+    assert not forced[1].eul_grid_forcing_field.get().any()
+    # the plain step of a simulator with forcing leaves the forcing alone and equals a simulator without forcing
+    forced[2].navier_stokes_timestep(dt=dt, free_stream_velocity=fs)
+    plain.flow_time_step(dt=dt, free_stream_velocity=fs)
+    assert np.array_equal(forced[2].eul_grid_forcing_field.get(), f0)
+    assert_close(forced[2].vorticity_field.get(), plain.vorticity_field.get(), real_t, factor=1.0,
+                 what="plain step of a forced simulator")
+    if dim == 3:
+        assert forced[2].rotational_form_navier_stokes_timestep is not None
+    transport = cls(flow_type="passive_scalar", **dict(kw, with_free_stream_flow=False))
+    name = "scalar_advection_and_diffusion_timestep" if dim == 3 else "advection_and_diffusion_timestep"
+    assert callable(getattr(transport, name))
