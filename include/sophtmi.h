@@ -310,6 +310,10 @@ int smi_ib_penalty_force(smi_ctx* ctx, void* lag_forcing, void* velocity_mismatc
                          const void* body_velocity, const void* position_mismatch, int64_t n,
                          double stiffness, double damping);
 
+/* The same three kernels one at a time, as the reference exposes them (static methods of
+ * VirtualBoundaryForcingMPI, :278-331): out = a x + b y on n device-resident doubles (out may be x or y). */
+int smi_ib_axpby(smi_ctx* ctx, void* out, double a, const void* x, double b, const void* y, int64_t n);
+
 /* Forcing grids of framed bodies formed on the device (replaces the host arithmetic of sopht's
  * SphereForcingGrid / CosseratRodSurfaceForcingGrid compute_lag_grid_position_field,
  * compute_lag_grid_velocity_field and transfer_forcing_from_grid_to_body; call sites

@@ -431,6 +431,23 @@ extern "C" int smi_ib_mismatch_step(smi_ctx* c, void* position_mismatch, const v
   return 0;
 }
 
+// out = a x + b y on n doubles: each of the three pointwise kernels of VirtualBoundaryForcingMPI.py:278-331 on its own
+// (velocity mismatch: 1, flow, -1, body; position mismatch: 1, itself, dt, velocity mismatch; penalty force: k, position
+// mismatch, c, velocity mismatch).  a x is formed first and b y added to it in one fused step.
+__global__ void __launch_bounds__(256) k_axpby_f64(double* __restrict__ out, double a, const double* __restrict__ x,
+                                                   double b, const double* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fma(b, y[i], a * x[i]);
+}
+
+extern "C" int smi_ib_axpby(smi_ctx* c, void* out, double a, const void* x, double b, const void* y, int64_t n) {
+  SMI_REQUIRE(c && out && x && y && n >= 0, "smi_ib_axpby: bad argument");
+  if (n == 0) return 0;
+  k_axpby_f64<<<(int)((n + 255) / 256), 256, 0, c->stream>>>((double*)out, a, (const double*)x, b, (const double*)y, n);
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
 // VirtualBoundaryForcingMPI.py:278-331, the three pointwise kernels in one: velocity mismatch = interpolated flow
 // velocity - body velocity, force = k * position mismatch + c * velocity mismatch.  n = dim * nodes doubles.
 __global__ void __launch_bounds__(256) k_penalty_force(double* __restrict__ force, double* __restrict__ vel_mismatch,

@@ -107,6 +107,7 @@ SIGNATURES = {
     "smi_ib_spread_fused": [_p, _p, _p, _p, _i64, _d, _d, _i64p, _i],
     "smi_ib_mismatch_step": [_p, _p, _p, _i64, _d],
     "smi_ib_penalty_force": [_p, _p, _p, _p, _p, _p, _i64, _d, _d],
+    "smi_ib_axpby": [_p, _p, _d, _p, _d, _p, _i64],
     "smi_ib_frame_nodes": [_p, _p, _p, _p, _p, _p, _p, _i, _i64],
     "smi_ib_frame_loads": [_p, _p, _p, _p, _p, _i, _i64],
     "smi_set_ordered_spread": [_p, _i],

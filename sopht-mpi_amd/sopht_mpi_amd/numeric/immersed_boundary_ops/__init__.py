@@ -283,6 +283,35 @@ class VirtualBoundaryForcingMPI:
         comm.gather_local_field(self.global_lag_grid_velocity_mismatch_field,
                                 self.local_lag_grid_velocity_mismatch_field.get())
 
+    # ---------------------------------------------------------------- the pointwise kernels, one at a time
+    @staticmethod
+    def _axpby(out, a, x, b, y):
+        dst = as_ptr(out)     # TypeError for anything but a device array
+        call("smi_ib_axpby", out.ctx.handle, dst, float(a), x.tracked_ptr(), float(b), y.tracked_ptr(), out.size)
+
+    @staticmethod
+    def compute_lag_grid_velocity_mismatch_field(lag_grid_velocity_mismatch_field, lag_grid_flow_velocity_field,
+                                                 lag_grid_body_velocity_field):
+        """:278-293 on device-resident float64 arrays: flow velocity - body velocity."""
+        VirtualBoundaryForcingMPI._axpby(lag_grid_velocity_mismatch_field, 1.0, lag_grid_flow_velocity_field, -1.0,
+                                         lag_grid_body_velocity_field)
+
+    @staticmethod
+    def update_lag_grid_position_mismatch_field_via_euler_forward(lag_grid_position_mismatch_field,
+                                                                  lag_grid_velocity_mismatch_field, dt):
+        """:295-310: position mismatch += dt * velocity mismatch."""
+        VirtualBoundaryForcingMPI._axpby(lag_grid_position_mismatch_field, 1.0, lag_grid_position_mismatch_field, dt,
+                                         lag_grid_velocity_mismatch_field)
+
+    @staticmethod
+    def compute_lag_grid_forcing_field(lag_grid_forcing_field, lag_grid_position_mismatch_field,
+                                       lag_grid_velocity_mismatch_field, virtual_boundary_stiffness_coeff,
+                                       virtual_boundary_damping_coeff):
+        """:312-331: the penalty force of the virtual boundary method."""
+        VirtualBoundaryForcingMPI._axpby(lag_grid_forcing_field, virtual_boundary_stiffness_coeff,
+                                         lag_grid_position_mismatch_field, virtual_boundary_damping_coeff,
+                                         lag_grid_velocity_mismatch_field)
+
     # ---------------------------------------------------------------- interaction
     def _upload_lagrangian_state(self, global_lag_grid_position_field, global_lag_grid_velocity_field):
         m = self.local_num_lag_nodes

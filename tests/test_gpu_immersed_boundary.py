@@ -140,3 +140,25 @@ def test_interactor_api_and_grid_deviation(smi):
     inter.time_step(dt=1e-3)
     sim.time_step(dt=1e-3, free_stream_velocity=[1.0, 0.0, 0.0])
     assert np.all(np.isfinite(sim.vorticity_field.get()))
+
+
+def test_pointwise_kernels_one_at_a_time(smi):
+    """VirtualBoundaryForcingMPI.py:278-331: the velocity mismatch, the Euler-forward update of the position mismatch
+    and the penalty force as separate calls on device arrays."""
+    from sopht_mpi_amd.numeric.immersed_boundary_ops import VirtualBoundaryForcingMPI as VBF
+    from sopht_mpi_amd.utils import MPIConstruct3D
+
+    ctx = MPIConstruct3D(16, 16, 16, real_t=np.float32).device_context(2)
+    rng = np.random.default_rng(21)
+    flow, body, pm = (rng.standard_normal((3, 77)) for _ in range(3))
+    d_flow, d_body, d_pm = ctx.from_numpy(flow), ctx.from_numpy(body), ctx.from_numpy(pm)
+    d_vm, d_force = ctx.zeros((3, 77), np.float64), ctx.zeros((3, 77), np.float64)
+    VBF.compute_lag_grid_velocity_mismatch_field(d_vm, d_flow, d_body)
+    assert np.array_equal(d_vm.get(), flow - body)
+    VBF.update_lag_grid_position_mismatch_field_via_euler_forward(d_pm, d_vm, 0.125)
+    np.testing.assert_allclose(d_pm.get(), pm + 0.125 * (flow - body), rtol=0, atol=4e-16 * np.abs(pm).max())
+    VBF.compute_lag_grid_forcing_field(d_force, d_pm, d_vm, -3.0e2, -1.5e1)
+    want = -3.0e2 * d_pm.get() + -1.5e1 * (flow - body)
+    np.testing.assert_allclose(d_force.get(), want, rtol=0, atol=4e-16 * np.abs(want).max())
+    with pytest.raises(TypeError):
+        VBF.compute_lag_grid_velocity_mismatch_field(np.zeros((3, 4)), d_flow, d_body)
