@@ -413,6 +413,9 @@ int smi2d_ib_interpolate(smi_ctx* ctx, void* lag_field, const void* eul_field, c
                          const void* nearest_index, int64_t m, int ncomp, double dx);
 int smi2d_ib_spread(smi_ctx* ctx, void* eul_field, const void* lag_field, const void* weights,
                     const void* nearest_index, int64_t m, int ncomp, int ghost_sum);
+/* MPIGhostSumCommunicator2D.ghost_sum (clear_only = 0) and clear_ghost_cells (clear_only != 0) on their own
+ * (EulerianLagrangianGridCommunicatorMPI2D.py:563-652) */
+int smi2d_ghost_sum(smi_ctx* ctx, void* field, int ncomp, int clear_only);
 
 #ifdef __cplusplus
 }

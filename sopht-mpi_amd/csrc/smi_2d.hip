@@ -853,6 +853,19 @@ extern "C" int smi2d_ib_spread(smi_ctx* c, void* eul_field, const void* lag_fiel
   return 0;
 }
 
+// MPIGhostSumCommunicator2D.ghost_sum / clear_ghost_cells on their own
+// (EulerianLagrangianGridCommunicatorMPI2D.py:521-652): the ghost rows are added to the neighbouring ranks' edge rows,
+// then every ghost cell is zeroed; clear_only != 0 skips the sum
+extern "C" int smi2d_ghost_sum(smi_ctx* c, void* field, int ncomp, int clear_only) {
+  SMI_CHECK(require_2d(c, "smi2d_ghost_sum"));
+  SMI_REQUIRE(field && ncomp >= 1 && ncomp <= 2, "smi2d_ghost_sum: bad argument");
+  if (!clear_only) SMI_CHECK(ghost_sum2(c, field, ncomp));
+  G2 P = geo2(c);
+  SMI_DISPATCH(c, { k2_clear_ghosts<T><<<nblocks(P.n * ncomp), kB, 0, c->stream>>>((T*)field, P, ncomp); });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
 // MPIGhostCommunicator2D.exchange_scalar_field_init / exchange_vector_field_init (utils/mpi_utils_2d.py:286-420)
 extern "C" int smi2d_halo_exchange(smi_ctx* c, void* field, int ncomp) {
   SMI_CHECK(require_2d(c, "smi2d_halo_exchange"));

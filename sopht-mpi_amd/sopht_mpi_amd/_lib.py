@@ -135,6 +135,7 @@ SIGNATURES = {
     "smi2d_ib_weights": [_p, _p, _p, C.c_int64, _d, _i],
     "smi2d_ib_interpolate": [_p, _p, _p, _p, _p, C.c_int64, _i, _d],
     "smi2d_ib_spread": [_p, _p, _p, _p, _p, C.c_int64, _i, _i],
+    "smi2d_ghost_sum": [_p, _p, _i, _i],
     "smi_set_forcing_support": [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "smi_flow_step_ns3d": [_p, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _i, _dp, _dp, _dp, _i, _i],
     "smi_flow_step_ns3d_swap": [_p, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _i, _dp, _dp, _dp, _i, _i,

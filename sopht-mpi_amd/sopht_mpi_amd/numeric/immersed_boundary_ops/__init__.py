@@ -138,6 +138,46 @@ class EulerianLagrangianGridCommunicatorMPI2D:
              self.n_components, 1)
 
 
+class _GhostSumCommunicator:
+    """What the Eulerian-Lagrangian communicators use after a spread, as a class of its own like the reference's
+    (EulerianLagrangianGridCommunicatorMPI3D.py:592-840, ...MPI2D.py:521-652): ``ghost_sum`` adds what landed in this
+    rank's ghost cells to the neighbours' edge cells and zeroes the ghosts, ``clear_ghost_cells`` only zeroes them.
+    Scalar fields, or vector fields with the components leading."""
+
+    grid_dim = None
+
+    def __init__(self, ghost_size, mpi_construct):
+        if ghost_size < 0 or not isinstance(ghost_size, (int, np.integer)):
+            raise ValueError(f"Ghost size {ghost_size} needs to be an integer >= 0 for field communication.")
+        self.mpi_construct = mpi_construct
+        self.ghost_size = int(ghost_size)
+        self.ctx = mpi_construct.device_context(self.ghost_size)
+        self.field_size = np.asarray(mpi_construct.local_grid_size) + 2 * self.ghost_size
+
+    def _ncomp(self, field):
+        return 1 if field.ndim == self.grid_dim else int(field.shape[0])
+
+
+class MPIGhostSumCommunicator3D(_GhostSumCommunicator):
+    grid_dim = 3
+
+    def ghost_sum(self, local_field):
+        call("smi_ghost_sum", self.ctx.handle, as_ptr(local_field), self._ncomp(local_field))
+
+    def clear_ghost_cells(self, field):
+        call("smi_clear_ghost_cells", self.ctx.handle, as_ptr(field), self._ncomp(field))
+
+
+class MPIGhostSumCommunicator2D(_GhostSumCommunicator):
+    grid_dim = 2
+
+    def ghost_sum(self, local_field):
+        call("smi2d_ghost_sum", self.ctx.handle, as_ptr(local_field), self._ncomp(local_field), 0)
+
+    def clear_ghost_cells(self, field):
+        call("smi2d_ghost_sum", self.ctx.handle, as_ptr(field), self._ncomp(field), 1)
+
+
 class VirtualBoundaryForcingMPI:
     """VirtualBoundaryForcingMPI.py:21-459.  3D as described below; 2D runs the
     communicator's four kernels one after the other and forms the penalty force with a fifth.
@@ -478,4 +518,4 @@ class DeviceResidentNodes:
 
 
 __all__ = ["DeviceResidentNodes", "EulerianLagrangianGridCommunicatorMPI2D", "EulerianLagrangianGridCommunicatorMPI3D",
-           "VirtualBoundaryForcingMPI"]
+           "MPIGhostSumCommunicator2D", "MPIGhostSumCommunicator3D", "VirtualBoundaryForcingMPI"]

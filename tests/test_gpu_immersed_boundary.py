@@ -162,3 +162,29 @@ def test_pointwise_kernels_one_at_a_time(smi):
     np.testing.assert_allclose(d_force.get(), want, rtol=0, atol=4e-16 * np.abs(want).max())
     with pytest.raises(TypeError):
         VBF.compute_lag_grid_velocity_mismatch_field(np.zeros((3, 4)), d_flow, d_body)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_ghost_sum_communicator_classes(smi, dim):
+    """MPIGhostSumCommunicator3D / 2D on one rank: every neighbour is absent, so the ghost sum leaves the interior
+    as it is and zeroes the ghost cells, exactly like clear_ghost_cells."""
+    from oracle import immersed_boundary as oib
+    from sopht_mpi_amd.numeric import immersed_boundary_ops as ibo
+    from sopht_mpi_amd.utils import MPIConstruct2D, MPIConstruct3D
+
+    g, n = 2, (8, 12, 16)[-dim:]
+    construct = (MPIConstruct3D if dim == 3 else MPIConstruct2D)(*n, real_t=np.float32)
+    comm = (ibo.MPIGhostSumCommunicator3D if dim == 3 else ibo.MPIGhostSumCommunicator2D)(g, construct)
+    assert list(comm.field_size) == [k + 2 * g for k in n]
+    rng = np.random.default_rng(5)
+    for ncomp in (None, dim):
+        shape = tuple(k + 2 * g for k in n) if ncomp is None else (ncomp,) + tuple(k + 2 * g for k in n)
+        host = rng.standard_normal(shape).astype(np.float32)
+        want = host.copy()
+        oib.clear_ghost_cells(want if ncomp else want[None], g, dim)
+        for method in (comm.ghost_sum, comm.clear_ghost_cells):
+            dev = comm.ctx.from_numpy(host)
+            method(dev)
+            assert np.array_equal(dev.get(), want)
+    with pytest.raises(ValueError):
+        type(comm)(-1, construct)
