@@ -599,6 +599,7 @@ extern "C" int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* c, const void*
 
 extern "C" int smi2d_poisson_destroy(smi_poisson2d* p) {
   if (!p) return 0;
+  if (p->ctx) hipStreamSynchronize(p->ctx->stream);  // solves and captured steps still in flight use what is freed here
   if (p->fwd) hipfftDestroy(p->fwd);
   if (p->inv) hipfftDestroy(p->inv);
   hipFree(p->real_buf);
@@ -924,6 +925,8 @@ int step2_launches(smi_ctx* c, smi_poisson2d* p, T* w, T* vel, T* psi, T* buf, T
 }
 
 void drop_step_graph(smi_poisson2d* p) {
+  // replays of the old graph may still be running (a rare event: the arrays of a simulator do not change)
+  if (p->step_exec && p->ctx) hipStreamSynchronize(p->ctx->stream);
   if (p->step_exec) hipGraphExecDestroy(p->step_exec);
   if (p->step_graph) hipGraphDestroy(p->step_graph);
   p->step_exec = nullptr;
