@@ -233,3 +233,34 @@ def test_2d_virtual_boundary_forcing(smi, real_t):
         pos = pos + 1e-3 * rng.standard_normal((2, m)) * 0.1
     assert_close(gpu.local_lag_grid_position_mismatch_field.get(), cpu.lag_position_mismatch, np.float64,
                  factor=1, what="2D position mismatch")
+
+
+def test_2d_captured_step_follows_its_arguments(smi):
+    """The one-call 2D step is replayed from a captured graph on a single rank.  A replay is only valid for the arrays
+    and tables it was captured with: when one of them changes (a new scratch array here, then another free stream,
+    then a step without free stream values changing the coefficients only) the step must still match the oracle."""
+    from sopht_mpi_amd.simulator import UnboundedFlowSimulator2D
+
+    real_t = np.float32
+    kw = dict(grid_size=(32, 48), x_range=1.0, kinematic_viscosity=5e-3, flow_type="navier_stokes", real_t=real_t,
+              with_free_stream_flow=True)
+    gpu, cpu = UnboundedFlowSimulator2D(**kw), OracleSim2D(**kw)
+    x, y = cpu.position_field
+    w0 = np.exp(-((x - 0.45) ** 2 + (y - 0.3) ** 2) / (2 * 0.06**2)).astype(real_t)
+    gpu.primary_scalar_field[...] = w0
+    cpu.primary_scalar_field[...] = w0
+    for sim in (gpu, cpu):
+        sim.compute_velocity_from_vorticity()
+    fs = np.array([1.0, -0.5])
+    for step in range(10):
+        if step == 5:
+            gpu.buffer_scalar_field = gpu.ctx.zeros(gpu.buffer_scalar_field.shape)   # another array: new capture
+        if step == 7:
+            fs = np.array([-0.25, 0.75])                                              # coefficients only: same graph
+        dt = cpu.compute_stable_timestep(dt_prefac=0.5 if step % 2 else 0.25)         # dt changes every step
+        gpu.time_step(dt=dt, free_stream_velocity=fs)
+        cpu.time_step(dt, free_stream_velocity=fs)
+        assert_close(gpu.primary_scalar_field.get(), cpu.primary_scalar_field, real_t, factor=1.0 + 0.5 * step,
+                     what=f"2D vorticity step {step}")
+        assert_close(gpu.velocity_field.get(), cpu.velocity_field, real_t, factor=1.0 + 0.5 * step,
+                     what=f"2D velocity step {step}")
