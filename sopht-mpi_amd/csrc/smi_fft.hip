@@ -550,12 +550,13 @@ constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 //   green                  : [ky folded ny+1][kz folded nz+1][KXP]    real
 // KXL = spectral columns per rank (kx in parity-split order j = 0..nx, cut into P ranges),
 // KXP = row pitch of bufB and of the Green's table (KXL rounded up to 16 columns: whole 128-byte
-// lines).  KXA = row pitch of the exchange buffers: KXP on one rank; KXL across ranks, where
-// every pad column would travel through both all-to-alls (19 % of their bytes at 8 ranks) and the
-// links, not the kernels, set the pace.  The y kernels then read rows of bufT past their end (the
+// lines).  KXA = row pitch of the exchange buffers: KXP on one rank; across ranks KXL rounded up to
+// 64 bytes, because every pad column travels through both all-to-alls (19 % of their bytes at 8 ranks
+// with whole lines) while rows on arbitrary 8-byte offsets make the y kernels write scattered partial
+// lines (see smi_pruned_create).  The y kernels then read rows of bufT past their end (the
 // next row's first columns stand in for the pad columns of a tile: finite values that only reach
-// pad columns of bufB) and store only columns below KXL; their partial-line stores cost
-// k_fft_y_inv 66 % on one GPU, which is why a single rank keeps the padded pitch.
+// pad columns of bufB) and store only columns below KXA; what is left of the partial-line cost is why
+// a single rank keeps the padded pitch.
 struct PGeo {
   int nz, ny, nx, nzl, P, nc, KXL, KXP, KXA, zb_shift;
   int c0;  // first component of this launch (components c0 .. c0 + nc - 1)
@@ -1154,8 +1155,20 @@ int smi_pruned_create(smi_poisson* p) {
   G.colbase = 0;
   G.KXL = (G.nx + 1 + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
-  // SMI_FFT_TIGHT_PITCH: the tight exchange pitch on a single rank as well (tests, measurements)
-  G.KXA = (G.P > 1 || getenv("SMI_FFT_TIGHT_PITCH")) ? G.KXL : G.KXP;
+  // Across ranks the exchange pitch is KXL rounded up to 64 bytes, not to whole lines: every pad column travels through
+  // both all-to-alls, but rows that start on arbitrary 8-byte offsets make the y kernels write scattered partial
+  // lines (measured on one GPU at 512^3, pitch unit 1 / 4 / 8 / 16 columns: y_inv 3.70 / 2.96 / 2.00 / 1.91 ms,
+  // y_fwd 2.52 / 2.45 / 2.26 / 1.96 ms, x_fwd 1.24 / 1.16 / 1.07 / 1.00 ms).  At 8 ranks that is 72 columns for 65:
+  // 11 % more bytes on the links than the tight pitch, 10 % fewer than whole lines, and all but 0.06 ms of the 0.3 ms
+  // per step the tight pitch costs the kernels of a rank.
+  // SMI_FFT_TIGHT_PITCH=<columns>: that rounding unit, on a single rank as well (tests, measurements; 1: exactly KXL).
+  {
+    const char* tp = getenv("SMI_FFT_TIGHT_PITCH");
+    const int dflt = (int)(64 / (2 * smi_elem_size(c)));
+    const int unit = tp ? atoi(tp) : dflt;
+    const int round_to = unit >= 1 && unit <= 16 ? unit : dflt;
+    G.KXA = (G.P > 1 || tp) ? (G.KXL + round_to - 1) / round_to * round_to : G.KXP;
+  }
   // z blocks of at most 16 planes and at most nz / 8 (one work item's elements share z % ZB)
   G.zb_shift = 0;  // largest power of two <= 16 that divides nz / 8
   while (G.zb_shift < 4 && (G.nz / 8) % (2 << G.zb_shift) == 0) ++G.zb_shift;
