@@ -16,6 +16,12 @@ rhs = ctx.field(3); sol = ctx.field(3)
 rhs[...] = np.random.default_rng(0).random((3,) + ctx.padded_shape, dtype=np.float32)
 p.vector_field_solve(sol, rhs)
 ctx.sync()
+import time
+t0 = time.perf_counter()
+for _ in range(reps):
+    p.vector_field_solve(sol, rhs)
+ctx.sync()
+print(f"  solve wall ms (no event timing): {(time.perf_counter() - t0) / reps * 1e3:.3f}")
 _lib.call("smi_prof_enable", ctx.handle, 1)
 for _ in range(reps):
     p.vector_field_solve(sol, rhs)
