@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-N = 1: 512^3 navier_stokes step on one MI355X (BASELINE.json metric).  N > 1 (launched by
+N = 1: 512^3 navier_stokes step on one MI355X (grid-point updates per second of a flow step).  N > 1 (launched by
 torch.distributed.run, one rank per GPU): the same 512^3 grid cut into N z-slabs (strong
 scaling: total work fixed).  Prints ONE JSON line on rank 0.
 """

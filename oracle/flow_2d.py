@@ -1,7 +1,7 @@
 """Oracle (test infrastructure): single-rank restatement of UnboundedFlowSimulator2D
 (sopht_mpi/simulator/flow/flow_simulators_mpi_2d.py: domain :110-145, fields :147-164, steps
-:260-298, time-step rule :300-321).  This is the CPU path BASELINE.json's first configuration
-(2D 256^2 vorticity step, one rank) runs on.
+:260-298, time-step rule :300-321).  This is the CPU path the reference's own single-rank case
+(2D 256^2 vorticity step, the Lamb-Oseen vortex) runs on.
 """
 import numpy as np
 

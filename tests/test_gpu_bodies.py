@@ -237,7 +237,7 @@ def test_ordered_spread_is_reproducible_and_follows_node_order(smi):
 
 
 def test_sphere_case_full_size_properties(smi):
-    """BASELINE configuration 4 at its real size: 256^3, sphere of diameter 0.4 with 192 points along the equator."""
+    """The reference's flow-past-sphere configuration at its real size: 256^3, sphere of diameter 0.4 with 192 points along the equator."""
     from sopht_mpi_amd.simulator import RigidBodyFlowInteractionMPI, UnboundedFlowSimulator3D
     from sopht_mpi_amd.simulator.immersed_body.forcing_grids import RigidSphereBody, SphereForcingGrid
 

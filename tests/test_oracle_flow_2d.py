@@ -1,4 +1,4 @@
-"""CPU: the 2D flow path of the oracle (BASELINE.json's first configuration runs on it).
+"""CPU: the 2D flow path of the oracle (the reference's own CPU-runnable case, the 256^2 Lamb-Oseen vortex, runs on it).
 
 The reference's 2D case is the Lamb-Oseen vortex carried by a free stream
 (examples/2d_examples/LambOseenVortexCase/lamb_oseen_vortex.py); it prints its errors

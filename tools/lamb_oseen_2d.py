@@ -1,4 +1,4 @@
-"""BASELINE.json configuration 1: the reference's 2D 256^2 case (Lamb-Oseen vortex advected by
+"""The reference's 2D 256^2 case (Lamb-Oseen vortex advected by
 a free stream while it diffuses, examples/2d_examples/LambOseenVortexCase/lamb_oseen_vortex.py
 :21-66, :122-180) on the CPU restatement, one process.  Prints the errors the reference prints.
 

@@ -1,4 +1,4 @@
-"""BASELINE.json configuration 5 shape (3D 384^3 flow past one Cosserat rod, immersed-boundary
+"""The shape of the reference's flow-past-rod configuration (3D 384^3 flow past one Cosserat rod, immersed-boundary
 surface forcing grid, vorticity filter of order 1) on one MI355X, with a rigid straight rod
 standing in for the PyElastica body (no body mechanics here): geometry as
 examples/3d_examples/FlowPastRodCase/flow_past_rod_case.py:40-60, 104-134, 314-316

@@ -1,4 +1,4 @@
-"""BASELINE.json configuration 4 (3D 256^3 flow past a rigid sphere with an immersed-boundary
+"""The reference's flow-past-sphere configuration (3D 256^3 flow past a rigid sphere with an immersed-boundary
 forcing grid) on one MI355X: navier_stokes_with_forcing, free stream (1, 0, 0), Re = 100,
 sphere D = 0.4 at (0.25, 0.5, 0.5) (examples/3d_examples/FlowPastSphereCase/
 flow_past_sphere_case.py:18-67), SphereForcingGrid with 1.875 D / dx
