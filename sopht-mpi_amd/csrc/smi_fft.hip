@@ -848,7 +848,9 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
                             : gbase + (size_t)(2 * L - 2 * m * L8 - 2 * L8 + 1) * G.KXP;
         gval[m] = ok ? gm[m < 4 ? goff_lo : goff_hi] : T(0);
       }
+#ifndef SMI_EXP_NO_FFT  // timing experiment only (wrong results): the kernel's loads and stores without its transforms
       fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
+#endif
       // the transform leaves element u + m L/8 in v[m], which is exactly what the first stage
       // of the inverse wants from this work item: scale in registers and go straight on
 #pragma unroll
@@ -857,7 +859,9 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
 #pragma unroll
         for (int m = 0; m < 8; ++m) a0[m] = ok ? SMI_Z_LOAD(&(next + m * mstep)[off]) : Cx<T>{0, 0};
       }
+#ifndef SMI_EXP_NO_FFT
       fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
+#endif
       if (pz == 0) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) res[m] = v[m];
