@@ -1,8 +1,9 @@
 """Checkpoint output (sopht_mpi/utils/mpi_io.py): the HDF5 subset writer / reader against the layouts of the HDF5
 file format specification, and ``MPIIO`` save -> load round trips shaped like the reference's own tests
 (tests/test_utils/test_mpi_io_3d.py, test_mpi_io_2d.py), for one rank and for several ranks writing their blocks
-of one file.  No HDF5 library exists in this environment: what is pinned here is the specification's byte layout of
-every structure the writer emits, and that the reader recovers every value."""
+of one file.  The interpreter that runs this suite has no HDF5 binding: what is pinned here is the specification's
+byte layout of every structure the writer emits, and that the reader recovers every value; the cross-checks against
+libhdf5 itself are in test_cpu_mpi_io_libhdf5.py."""
 import struct
 import xml.etree.ElementTree as ET
 
