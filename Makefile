@@ -12,7 +12,11 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) \
             -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-result -Wno-unused-value
 LDLIBS  := -L/opt/rocm/lib -lhipfft -lrccl -Wl,-rpath,/opt/rocm/lib
 
-all: $(OUT)
+STANDIN_DIR := tests/rccl_standin
+STANDIN_RCCL := $(STANDIN_DIR)/librccl_standin.so
+STANDIN_OUT := $(STANDIN_DIR)/libsophtmi_standin.so
+
+all: $(OUT) $(STANDIN_OUT)
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/sophtmi.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -21,7 +25,20 @@ $(OUT): $(OBJS)
 	mkdir -p $(dir $(OUT))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ $(LDLIBS)
 
-clean:
-	rm -f $(OBJS) $(OUT)
+# Test infrastructure: the same objects linked against a stand-in for librccl that carries the few RCCL calls of
+# the library between rank processes sharing one GPU (tests/rccl_standin/standin.cpp), so that the library's RCCL
+# branches run on a one-GPU box.  Never loaded unless a test names it in SOPHT_MPI_AMD_LIB.
+$(STANDIN_RCCL): $(STANDIN_DIR)/standin.cpp
+	g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $< -o $@ \
+	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 
-.PHONY: all clean
+$(STANDIN_OUT): $(OBJS) $(STANDIN_RCCL)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -L/opt/rocm/lib -lhipfft \
+	    -L$(STANDIN_DIR) -lrccl_standin -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,'$$ORIGIN'
+
+standin: $(STANDIN_OUT)
+
+clean:
+	rm -f $(OBJS) $(OUT) $(STANDIN_RCCL) $(STANDIN_OUT)
+
+.PHONY: all clean standin

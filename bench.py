@@ -287,6 +287,9 @@ def main():
     }
     if args.gpus > 1 and sim.ctx.transport != "rccl":
         out["invalid"] = "rehearsal over the host-staged transport on a shared GPU, not a multi-GPU measurement"
+    if os.environ.get("SOPHT_MPI_AMD_LIB"):
+        # another build of the library (a kernel variant, or the test build that carries the RCCL calls over sockets)
+        out["invalid"] = f"library override SOPHT_MPI_AMD_LIB={os.environ['SOPHT_MPI_AMD_LIB']}: not the in-tree library"
     out["roofline"] = roofline_from_profile(prof, counters, counters_source)
     out["kernels"] = {k: {"launches": v["launches"], "avg_ms": v["ms"] / v["launches"],
                           "median_ms": float(np.median(v["samples_ms"])) if v["samples_ms"] else None,

@@ -150,4 +150,4 @@ if flow_type != "passive_scalar":
     mv, want_mv = float(gpu.get_max_vorticity()), float(cpu.get_max_vorticity())
     assert abs(mv - want_mv) <= 1e-5 * abs(want_mv)
 world.barrier()
-print(f"rank {rank} ok")
+print(f"rank {rank} ok, transport {gpu.mpi_construct.device_context(g).transport}")

@@ -123,4 +123,4 @@ if interactor is not None:
 mv = gpu.get_max_vorticity()
 assert abs(float(mv) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(float(cpu.get_max_vorticity()))
 world.barrier()
-print(f"rank {rank} ok")
+print(f"rank {rank} ok, transport {gpu.mpi_construct.device_context(g).transport}")

@@ -1,0 +1,58 @@
+"""GPU, several ranks on one GPU: the library's RCCL branches (ncclSend / ncclRecv halo and ghost-sum groups, the
+grouped all-to-all of the FFT transposes on the communication stream, the pencil redistribution, the 2D all-gather,
+the all-reduce) against the single-rank oracle.
+
+RCCL refuses two ranks on one device, so these branches cannot run over RCCL itself on a one-GPU box.  Here the
+same library objects are linked against a stand-in for librccl (tests/rccl_standin/standin.cpp: the dozen RCCL
+entry points carried over Unix sockets between the rank processes, with every message's length checked against
+what the receiver expects) and the workers of tests/test_gpu_slabs.py run with SOPHT_MI_TRANSPORT=rccl.  What this
+pins: peers, counts, offsets and the send / receive order inside every group.  What it cannot show: a missing
+ordering between streams (the stand-in completes every call on the host)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from test_gpu_slabs import _failure_digest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STANDIN = os.path.join(ROOT, "tests", "rccl_standin", "libsophtmi_standin.so")
+
+
+def _run(worker, nranks, port, args):
+    if not os.path.exists(STANDIN):
+        pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["SOPHT_MI_TRANSPORT"] = "rccl"
+    env["SOPHT_MPI_AMD_LIB"] = STANDIN
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", worker)] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, _failure_digest(out)
+    for r in range(nranks):
+        assert f"rank {r} ok" in out.stdout
+    assert "transport rccl" in out.stdout, "the workers did not run over the RCCL branches"
+
+
+@pytest.mark.parametrize("nranks,flow_type,mode,grid", [
+    (2, "navier_stokes", "fused", "32x16x32"),
+    (4, "navier_stokes_with_forcing", "fused", "64x32x64 nofilter"),   # one exchange of u and w, ghost sum, transposes
+    (4, "navier_stokes", "unfused", "32x16x32"),
+    (8, "navier_stokes_with_forcing", "fused", "64x32x64"),
+    (4, "navier_stokes_with_forcing", "unfused", "64x32x64 pencil"),   # y faces, pencil <-> slab redistribution
+    (2, "navier_stokes_with_forcing", "unfused", "32x32x32 yslab"),
+])
+def test_slab_flow_step_over_the_rccl_branches(nranks, flow_type, mode, grid):
+    _run("_slab_worker.py", nranks, 29800 + nranks, [flow_type, mode] + grid.split())
+
+
+@pytest.mark.parametrize("nranks,flow_type,mode,grid", [
+    (2, "navier_stokes", "fused", "32x48"),
+    (4, "navier_stokes_with_forcing", "fused", "64x48"),
+    (4, "navier_stokes_with_forcing", "unfused", "64x48 double"),
+])
+def test_row_slab_2d_flow_over_the_rccl_branches(nranks, flow_type, mode, grid):
+    _run("_rows_worker_2d.py", nranks, 29900 + nranks, [flow_type, mode] + grid.split())
