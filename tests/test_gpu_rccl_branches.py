@@ -6,8 +6,11 @@ RCCL refuses two ranks on one device, so these branches cannot run over RCCL its
 same library objects are linked against a stand-in for librccl (tests/rccl_standin/standin.cpp: the dozen RCCL
 entry points carried over Unix sockets between the rank processes, with every message's length checked against
 what the receiver expects) and the workers of tests/test_gpu_slabs.py run with SOPHT_MI_TRANSPORT=rccl.  What this
-pins: peers, counts, offsets and the send / receive order inside every group.  What it cannot show: a missing
-ordering between streams (the stand-in completes every call on the host)."""
+pins: peers, counts, offsets and the send / receive order inside every group.  The stand-in queues its work on the
+stream each call names, as RCCL does, and the "held back" cases delay every transfer by some milliseconds: a kernel
+that is not ordered behind the exchange that feeds it (the interior / edge split of the one-pass advection +
+diffusion kernel, the component pipeline of the Poisson solve on its communication stream) would then read stale
+bytes and miss the oracle."""
 import os
 import subprocess
 import sys
@@ -21,13 +24,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STANDIN = os.path.join(ROOT, "tests", "rccl_standin", "libsophtmi_standin.so")
 
 
-def _run(worker, nranks, port, args):
+def _run(worker, nranks, port, args, delay_ms=0):
     if not os.path.exists(STANDIN):
         pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env["SOPHT_MI_TRANSPORT"] = "rccl"
     env["SOPHT_MPI_AMD_LIB"] = STANDIN
+    env["SMI_STANDIN_DELAY_MS"] = str(delay_ms)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", worker)] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -56,3 +60,13 @@ def test_slab_flow_step_over_the_rccl_branches(nranks, flow_type, mode, grid):
 ])
 def test_row_slab_2d_flow_over_the_rccl_branches(nranks, flow_type, mode, grid):
     _run("_rows_worker_2d.py", nranks, 29900 + nranks, [flow_type, mode] + grid.split())
+
+
+@pytest.mark.parametrize("worker,nranks,args", [
+    ("_slab_worker.py", 2, "navier_stokes fused 32x16x32"),
+    ("_slab_worker.py", 4, "navier_stokes_with_forcing fused 64x32x64 nofilter"),
+    ("_slab_worker.py", 4, "navier_stokes_with_forcing unfused 64x32x64 pencil"),
+    ("_rows_worker_2d.py", 4, "navier_stokes_with_forcing fused 64x48"),
+])
+def test_transfers_held_back_by_milliseconds(worker, nranks, args):
+    _run(worker, nranks, 29950 + nranks, args.split(), delay_ms=4)
