@@ -70,3 +70,43 @@ def test_row_slab_2d_flow_over_the_rccl_branches(nranks, flow_type, mode, grid):
 ])
 def test_transfers_held_back_by_milliseconds(worker, nranks, args):
     _run(worker, nranks, 29950 + nranks, args.split(), delay_ms=4)
+
+
+@pytest.mark.parametrize("n,nranks", [(512, 8), (512, 4), (512, 2)])
+def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, nranks):
+    """The scaling configuration itself - the 512^3 benchmark workload cut into 8 z-slabs of 64 planes, 65 spectral
+    columns per rank in rows of 72 - run over the RCCL branches for two steps and compared with the single-rank run
+    of the same workload: time step, maximum vorticity, divergence norm, and the sum of every interior plane of the
+    vorticity and of |velocity| (a slab boundary that went wrong shows in the planes next to it)."""
+    import json
+
+    import numpy as np
+
+    if not os.path.exists(STANDIN):
+        pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
+    worker = os.path.join(ROOT, "tests", "_full_size_ranks_worker.py")
+    out_dir = str(tmp_path)
+    env = dict(os.environ)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SOPHT_MPI_AMD_LIB", "SOPHT_MI_TRANSPORT"):
+        env.pop(key, None)
+    single = subprocess.run([sys.executable, worker, str(n), "2", out_dir], env=env, capture_output=True, text=True,
+                            timeout=600)
+    assert single.returncode == 0, _failure_digest(single)
+    env["SOPHT_MI_TRANSPORT"] = "rccl"
+    env["SOPHT_MPI_AMD_LIB"] = STANDIN
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(29990 + nranks), worker, str(n), "2", out_dir]
+    slabs = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert slabs.returncode == 0, _failure_digest(slabs)
+    assert slabs.stdout.count("transport rccl") == nranks
+    a = json.load(open(os.path.join(out_dir, "diag_1.json")))
+    b = json.load(open(os.path.join(out_dir, f"diag_{nranks}.json")))
+    assert abs(a["dt"] - b["dt"]) <= 1e-6 * a["dt"] and abs(a["dt_after"] - b["dt_after"]) <= 1e-5 * a["dt_after"]
+    assert abs(a["max_vorticity"] - b["max_vorticity"]) <= 1e-5 * a["max_vorticity"]
+    assert abs(a["divergence_l2"] - b["divergence_l2"]) <= 1e-3 * a["divergence_l2"] + 1e-7
+    whole = np.load(os.path.join(out_dir, "planes_1_0.npy"))
+    parts = np.concatenate([np.load(os.path.join(out_dir, f"planes_{nranks}_{r}.npy")) for r in range(nranks)], axis=1)
+    assert whole.shape == parts.shape == (6, n)
+    for k in range(6):
+        scale = np.abs(whole[k]).max()
+        assert np.abs(whole[k] - parts[k]).max() <= 2e-5 * scale, (k, np.abs(whole[k] - parts[k]).max(), scale)
