@@ -72,6 +72,25 @@ def test_transfers_held_back_by_milliseconds(worker, nranks, args):
     _run(worker, nranks, 29950 + nranks, args.split(), delay_ms=4)
 
 
+def _single_and_slabs(worker_name, n, steps, nranks, port, out_dir, extra_env=None):
+    """Runs a worker on one rank (in-tree library) and on `nranks` ranks over the RCCL branches."""
+    worker = os.path.join(ROOT, "tests", worker_name)
+    env = dict(os.environ)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SOPHT_MPI_AMD_LIB", "SOPHT_MI_TRANSPORT"):
+        env.pop(key, None)
+    env.update(extra_env or {})
+    single = subprocess.run([sys.executable, worker, str(n), str(steps), out_dir], env=env, capture_output=True,
+                            text=True, timeout=600)
+    assert single.returncode == 0, _failure_digest(single)
+    env["SOPHT_MI_TRANSPORT"] = "rccl"
+    env["SOPHT_MPI_AMD_LIB"] = STANDIN
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker, str(n), str(steps), out_dir]
+    slabs = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert slabs.returncode == 0, _failure_digest(slabs)
+    assert slabs.stdout.count("transport rccl") == nranks
+
+
 @pytest.mark.parametrize("n,nranks", [(512, 8), (512, 4), (512, 2)])
 def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, nranks):
     """The scaling configuration itself - the 512^3 benchmark workload cut into 8 z-slabs of 64 planes, 65 spectral
@@ -84,21 +103,8 @@ def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, n
 
     if not os.path.exists(STANDIN):
         pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
-    worker = os.path.join(ROOT, "tests", "_full_size_ranks_worker.py")
     out_dir = str(tmp_path)
-    env = dict(os.environ)
-    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SOPHT_MPI_AMD_LIB", "SOPHT_MI_TRANSPORT"):
-        env.pop(key, None)
-    single = subprocess.run([sys.executable, worker, str(n), "2", out_dir], env=env, capture_output=True, text=True,
-                            timeout=600)
-    assert single.returncode == 0, _failure_digest(single)
-    env["SOPHT_MI_TRANSPORT"] = "rccl"
-    env["SOPHT_MPI_AMD_LIB"] = STANDIN
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(29990 + nranks), worker, str(n), "2", out_dir]
-    slabs = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert slabs.returncode == 0, _failure_digest(slabs)
-    assert slabs.stdout.count("transport rccl") == nranks
+    _single_and_slabs("_full_size_ranks_worker.py", n, 2, nranks, 29990 + nranks, out_dir)
     a = json.load(open(os.path.join(out_dir, "diag_1.json")))
     b = json.load(open(os.path.join(out_dir, f"diag_{nranks}.json")))
     assert abs(a["dt"] - b["dt"]) <= 1e-6 * a["dt"] and abs(a["dt_after"] - b["dt_after"]) <= 1e-5 * a["dt_after"]
@@ -110,3 +116,31 @@ def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, n
     for k in range(6):
         scale = np.abs(whole[k]).max()
         assert np.abs(whole[k] - parts[k]).max() <= 2e-5 * scale, (k, np.abs(whole[k] - parts[k]).max(), scale)
+
+
+def test_rod_configuration_over_four_slabs_equals_the_single_rank_run(tmp_path):
+    """The shape of the reference's flow-past-rod configuration (384^3, filter of order 1, 5 760 surface nodes on an
+    inclined rod) on 4 slabs over the RCCL branches against the single-rank run: the slabs take the host path of the
+    forcing grid and the Lagrangian communicators, the single rank forms its nodes on the device."""
+    import json
+
+    import numpy as np
+
+    if not os.path.exists(STANDIN):
+        pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
+    n, nranks, out_dir = 384, 4, str(tmp_path)
+    _single_and_slabs("_rod_ranks_worker.py", n, 3, nranks, 29985, out_dir, {"SOPHT_MI_ORDERED_SPREAD": "1"})
+    a = json.load(open(os.path.join(out_dir, "diag_1.json")))
+    b = json.load(open(os.path.join(out_dir, f"diag_{nranks}.json")))
+    assert a["lag_nodes"] == b["lag_nodes"] == 5760
+    assert abs(a["dt"] - b["dt"]) <= 1e-5 * a["dt"]
+    assert abs(a["max_vorticity"] - b["max_vorticity"]) <= 1e-4 * a["max_vorticity"]
+    assert abs(a["grid_deviation_l2"] - b["grid_deviation_l2"]) <= 1e-4 * a["grid_deviation_l2"]
+    fa, fb = np.array(a["net_force_on_rod"]), np.array(b["net_force_on_rod"])
+    assert np.abs(fa - fb).max() <= 1e-4 * np.abs(fa).max(), (fa, fb)
+    whole = np.load(os.path.join(out_dir, "planes_1_0.npy"))
+    parts = np.concatenate([np.load(os.path.join(out_dir, f"planes_{nranks}_{r}.npy")) for r in range(nranks)], axis=1)
+    assert whole.shape == parts.shape == (6, n)
+    for k in range(6):
+        scale = np.abs(whole[k]).max()
+        assert np.abs(whole[k] - parts[k]).max() <= 1e-4 * scale, (k, np.abs(whole[k] - parts[k]).max(), scale)
