@@ -48,6 +48,7 @@ def _run(worker, nranks, port, args, delay_ms=0):
     (8, "navier_stokes_with_forcing", "fused", "64x32x64"),
     (4, "navier_stokes_with_forcing", "unfused", "64x32x64 pencil"),   # y faces, pencil <-> slab redistribution
     (2, "navier_stokes_with_forcing", "unfused", "32x32x32 yslab"),
+    (8, "navier_stokes_with_forcing", "unfused", "64x64x64 pencil"),   # 4 x 2 ranks: the reference's default at 8
 ])
 def test_slab_flow_step_over_the_rccl_branches(nranks, flow_type, mode, grid):
     _run("_slab_worker.py", nranks, 29800 + nranks, [flow_type, mode] + grid.split())
