@@ -892,33 +892,36 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
 }
 
 // ------------------------------------------------------------------------- x forward
-// Real rows of 2L = nx points -> nx + 1 complex, through an L-point complex FFT of the
-// packed row z[n] = x[2n] + i x[2n+1] (zero padded to 2L, hence again an even / odd pair
-// of L-point transforms) and the real-FFT untangle
-//   X[k] = (Z[k] + conj Z[M-k]) / 2 - (i/2) e^{-2 pi i k / 2M} (Z[k] - conj Z[M-k]),  M = nx.
-// Even k only need the even transform, odd k only the odd one.  Output column order:
-// j = 0..L holds kx = 2j, j = L+1..2L holds kx = 2(j-L-1)+1.
-// Lanes run along a row: a work item loads and stores its own eight elements directly
-// (each a 256-byte or longer contiguous run per row), the tile is only used by the
-// transform stages and by the Z[M-k] lookup of the untangle.
+// Real rows of nx points, zero padded to 2 nx, at the half-sample-shifted frequencies k + 1/2 of the 2 nx-point
+// grid: X[k + 1/2] = sum_n x[n] exp(-2 pi i n (k + 1/2) / 2nx).  A real row has X[(2nx - 1 - k) + 1/2] =
+// conj X[k + 1/2], so the nx values at even k = 2 j are a complete set, all of them complex (no real-only columns as
+// the unshifted transform has at kx = 0 and at the Nyquist frequency: nx columns instead of nx + 1, whole 16-column
+// tiles for every power-of-two grid and rank count), and
+//   X[2 j + 1/2] = sum_{n < nx} (x[n] exp(-i pi n / 2nx)) exp(-2 pi i n j / nx):
+// ONE nx-point complex transform of the pre-twiddled row.  The shifted transform diagonalises the negacyclic
+// convolution; the Green's table is the shifted transform of the negacyclic (odd-wrapped) extension of the even
+// kernel, which is real again (see smi_greens_spectrum_shifted), and on the nx outputs that are kept the negacyclic
+// convolution of a row padded with nx zeros IS the linear convolution.
+// Lanes run along a row: a work item loads and stores its own eight elements directly (each a 256-byte or longer
+// contiguous run per row); the tile is only used by the transform stages.
 struct FieldGeo {
-  int g, px, vec2;  // vec2: rows may be accessed as aligned pairs of reals
+  int g, px, vec2;  // vec2: rows start on an 8-byte boundary (kept for the callers; the kernels do not need it)
   long long plane, vol;
 };
 
+// w * exp(-i pi m / 16): the pre-twiddle exp(-i pi n / 2L) of element n = u + m L/8 is the per-thread factor
+// exp(-i pi u / 2L) times this constant
 template <typename T>
-__device__ __forceinline__ Cx<T> load_pair(const T* p, bool vec2) {
-  if (vec2) return *reinterpret_cast<const Cx<T>*>(p);
-  return Cx<T>{p[0], p[1]};
-}
-template <typename T>
-__device__ __forceinline__ void store_pair(T* p, Cx<T> a, bool vec2) {
-  if (vec2) {
-    *reinterpret_cast<Cx<T>*>(p) = a;
-  } else {
-    p[0] = a.x;
-    p[1] = a.y;
-  }
+__device__ __forceinline__ Cx<T> mul_c32(Cx<T> w, int m) {
+  constexpr double c[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                           0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                           0.19509032201612826785};
+  constexpr double sn[8] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
+                            0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
+                            0.98078528040323044913};
+  if (m == 0) return w;
+  const T cc = (T)c[m], ss = (T)sn[m];
+  return Cx<T>{w.x * cc + w.y * ss, w.y * cc - w.x * ss};
 }
 
 // element offset of spectral column j of row (c, zl, y) in the exchange layout
@@ -935,52 +938,33 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
   FFT_KERNEL_PROLOGUE(true)
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
-  const Cx<T> w1 = tw4[1];  // exp(-i pi / 2L)
+  const Cx<T> wh = tw4[item ? u : 0];  // exp(-i pi u / 2L)
+  Cx<T> pre[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) pre[m] = mul_c32(wh, m);
   for (int it = 0; it < x_tiles<LG>(true); ++it) {
     const int y = (blockIdx.x * x_tiles<LG>(true) + it) * TS + t;
     const bool ok = y < G.ny && item;
     const T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
     const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
-    Cx<T> v[8], a0[8];
+    Cx<T> v[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) a0[m] = ok ? load_pair(row + 2 * (u + m * L8), F.vec2) : Cx<T>{0, 0};
+    for (int m = 0; m < 8; ++m) {
+      const T x = ok ? row[u + m * L8] : T(0);
+      v[m] = Cx<T>{x * pre[m].x, x * pre[m].y};
+    }
+    fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
+    if (ok) {
 #pragma unroll
-    for (int parity = 0; parity < 2; ++parity) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) v[m] = parity ? a0[m] * mul_c16(wu, m) : a0[m];
-      fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
-      Cx<T>* z = sel.next();
-      if (item) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) z[Lay::idx(u + m * L8, t)] = v[m];
-      }
-      __syncthreads();
-      if (ok) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int k = u + m * L8;
-          const int kp = parity ? L - 1 - k : (k ? L - k : 0);
-          const Cx<T> a = v[m], b = conj(z[Lay::idx(kp, t)]);
-          Cx<T> w = mul_c16(wu, m);  // exp(-i pi k / L)
-          if (parity) w = w * w1;
-          const Cx<T> sm = a + b, d = w * (a - b);
-          const Cx<T> X{(T)0.5 * (sm.x + d.y), (T)0.5 * (sm.y - d.x)};  // s/2 - (i/2) d
-          stream_store(&out[colA(G, rowbase, rank_stride, parity ? L + 1 + k : k)], X);
-        }
-        if (parity == 0 && u == 0) {
-          // kx = 2L (j = L): X = Re Z[0] - Im Z[0]
-          out[colA(G, rowbase, rank_stride, L)] = Cx<T>{v[0].x - v[0].y, T(0)};
-        }
-      }
-      sel.after_read();
+      for (int m = 0; m < 8; ++m) stream_store(&out[colA(G, rowbase, rank_stride, u + m * L8)], v[m]);
     }
   }
 }
 
 // ------------------------------------------------------------------------- x inverse
-// Z[k] = E[k] + i O[k], E = (X[k] + conj X[M-k]) / 2, O = (X[k] - conj X[M-k]) / 2 * e^{+2 pi i k / 2M},
-// formed per work item from its own eight columns and their mirror columns (both read
-// straight from the exchange layout), then the truncated inverse pair of L-point transforms.
+// x[n] = (1 / nx) Re[ exp(+i pi n / 2nx) sum_j X[2 j + 1/2] exp(+2 pi i n j / nx) ] for n < nx (the odd frequencies
+// are the conjugates of the even ones and double the real part; 1 / nx sits in the Green's table): one nx-point
+// inverse transform and the real part of the post-twiddled result.
 template <typename T, int LG>
 __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G, FieldGeo F,
@@ -988,45 +972,28 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
   FFT_KERNEL_PROLOGUE(true)
   const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
-  const Cx<T> w1 = tw4[1];
+  const Cx<T> wh = tw4[item ? u : 0];
+  Cx<T> pre[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) pre[m] = mul_c32(wh, m);
   for (int it = 0; it < x_tiles<LG>(false); ++it) {
     const int y = (blockIdx.x * x_tiles<LG>(false) + it) * TS + t;
     const bool ok = y < G.ny && item;
     T* row = field + (size_t)c * F.vol + (size_t)(zl + F.g) * F.plane + (size_t)(y + F.g) * F.px + F.g;
     const size_t rowbase = ((((size_t)c * G.P) * G.nzl + zl) * G.ny + y) * (size_t)G.KXA;
-    Cx<T> v[8], res[8];
+    Cx<T> v[8];
 #pragma unroll
-    for (int parity = 0; parity < 2; ++parity) {
-      Cx<T> xa[8], xb[8];
+    for (int m = 0; m < 8; ++m)
+      v[m] = ok ? stream_load(&in[colA(G, rowbase, rank_stride, u + m * L8)]) : Cx<T>{0, 0};
+    fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
+    if (ok) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int k = u + m * L8;
-        const int ja = parity ? L + 1 + k : k;
-        const int jb = parity ? 2 * L - k : L - k;  // mirror column M - kx in the same parity block
-        xa[m] = ok ? in[colA(G, rowbase, rank_stride, ja)] : Cx<T>{0, 0};
-        xb[m] = ok ? in[colA(G, rowbase, rank_stride, jb)] : Cx<T>{0, 0};
-      }
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        Cx<T> w = mul_c16(wu, m);
-        if (parity) w = w * w1;
-        const Cx<T> sm = xa[m] + conj(xb[m]), d = conj(w) * (xa[m] - conj(xb[m]));
-        v[m] = Cx<T>{(T)0.5 * (sm.x - d.y), (T)0.5 * (sm.y + d.x)};  // s/2 + (i/2) d
-      }
-      fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
-      if (parity == 0) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) res[m] = v[m];
-      } else if (ok) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-          store_pair(row + 2 * (u + m * L8), res[m] + conj(mul_c16(wu, m)) * v[m], F.vec2);
-      }
+      for (int m = 0; m < 8; ++m) row[u + m * L8] = v[m].x * pre[m].x + v[m].y * pre[m].y;  // Re(conj(pre) v)
     }
   }
 }
 
-// Folded, permuted, real Green's table from the full complex spectrum of the rocFFT path.
+// Folded real Green's table from the spectrum of smi_greens_spectrum_shifted (complex (2nz, 2ny, nx), real part).
 template <typename T>
 __global__ void __launch_bounds__(kThreads) k_fold_green(T* __restrict__ green, const T* __restrict__ ghat, PGeo G,
                                                          int rank, T norm) {
@@ -1036,13 +1003,9 @@ __global__ void __launch_bounds__(kThreads) k_fold_green(T* __restrict__ green, 
   const int jl = (int)(i % G.KXP);
   long long r = i / G.KXP;
   const int kzc = (int)(r % (G.nz + 1)), kyc = (int)(r / (G.nz + 1));
-  const int L = G.nx / 2;
   const int j = rank * G.KXL + jl;
   T val = T(0);
-  if (jl < G.KXL && j <= G.nx) {
-    const int kx = j <= L ? 2 * j : 2 * (j - L - 1) + 1;
-    val = ghat[2 * (((long long)kzc * (2 * G.ny) + kyc) * (G.nx + 1) + kx)] * norm;
-  }
+  if (jl < G.KXL && j < G.nx) val = ghat[2 * (((long long)kzc * (2 * G.ny) + kyc) * G.nx + j)] * norm;
   green[i] = val;
 }
 
@@ -1062,13 +1025,13 @@ int ilog2(int n) {
 
 }  // namespace
 
-int smi_greens_spectrum_rocfft(smi_ctx* c, int gnz, int gny, int gnx, double dx, double x_range, void** ghat_out);
+int smi_greens_spectrum_shifted(smi_ctx* c, int gnz, int gny, int gnx, double dx, double x_range, void** ghat_out);
 typedef int (*alltoall_fn)(smi_ctx*, const void*, void*, size_t);
 int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream);
 
 struct PrunedState {
   PGeo G;
-  int lgx, lgy, lgz;  // plan keys of the transform lengths nx/2, ny, nz
+  int lgx, lgy, lgz;  // plan keys of the transform lengths nx, ny, nz
   void* tw[3] = {nullptr, nullptr, nullptr};  // x, y, z twiddle tables (4L complex each)
   void* bufA = nullptr;
   void* bufT = nullptr;  // == bufA on a single rank
@@ -1134,18 +1097,17 @@ static int fold_greens_table(smi_ctx* c, PrunedState* s, const void* ghat) {
 
 // grids the pruned back end has plans for (what smi_poisson_supports reports)
 bool smi_pruned_supports(int gnz, int gny, int gnx) {
-  return gnx % 2 == 0 && plan_key(gnx / 2) && plan_key(gny) && plan_key(gnz) && gnx >= 16 && gny >= 8 && gnz >= 8 &&
-         gnx <= 4096 && gny <= 2048 && gnz <= 2048;
+  return plan_key(gnx) && plan_key(gny) && plan_key(gnz) && gnx >= 8 && gny >= 8 && gnz >= 8 && gnx <= 2048 &&
+         gny <= 2048 && gnz <= 2048;
 }
 
 int smi_pruned_create(smi_poisson* p) {
   smi_ctx* c = p->ctx;
-  SMI_REQUIRE(p->gnx % 2 == 0 && plan_key(p->gnx / 2) && plan_key(p->gny) && plan_key(p->gnz) && p->gnx >= 16 &&
-                  p->gny >= 8 && p->gnz >= 8,
-              "SMI_POISSON_PRUNED needs transform lengths nx/2, ny, nz that are powers of two or 192, 384, 768, "
-              "with nx >= 16, ny >= 8, nz >= 8 (got %d %d %d); power of two grid sizes always qualify",
+  SMI_REQUIRE(plan_key(p->gnx) && plan_key(p->gny) && plan_key(p->gnz) && p->gnx >= 8 && p->gny >= 8 && p->gnz >= 8,
+              "SMI_POISSON_PRUNED needs transform lengths nx, ny, nz that are powers of two (8 .. 2048) or 192, 384, 768 "
+              "(got %d %d %d)",
               p->gnz, p->gny, p->gnx);
-  SMI_REQUIRE(p->gnx <= 4096 && p->gny <= 2048 && p->gnz <= 2048, "SMI_POISSON_PRUNED: grid too large");
+  SMI_REQUIRE(p->gnx <= 2048 && p->gny <= 2048 && p->gnz <= 2048, "SMI_POISSON_PRUNED: grid too large");
   PrunedState* s = new PrunedState();
   p->pruned = s;
   PGeo& G = s->G;
@@ -1157,8 +1119,12 @@ int smi_pruned_create(smi_poisson* p) {
   G.nc = 3;
   G.c0 = 0;
   G.colbase = 0;
-  G.KXL = (G.nx + 1 + G.P - 1) / G.P;
+  G.KXL = (G.nx + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
+  // nx columns of a power-of-two grid make rows of a power-of-two pitch, and the column kernels walk down hundreds of
+  // rows at that stride: one more tile of (never touched) columns keeps their accesses spread over the memory
+  // channels (measured at 512^3: y_fwd 2.10 -> 1.9 ms)
+  if (G.KXP % 64 == 0) G.KXP += 16;
   // Across ranks the exchange pitch is KXL rounded up to 64 bytes, not to whole lines: every pad column travels through
   // both all-to-alls, but rows that start on arbitrary 8-byte offsets make the y kernels write scattered partial
   // lines (measured on one GPU at 512^3, pitch unit 1 / 4 / 8 / 16 columns: y_inv 3.70 / 2.96 / 2.00 / 1.91 ms,
@@ -1176,7 +1142,7 @@ int smi_pruned_create(smi_poisson* p) {
   // z blocks of at most 16 planes and at most nz / 8 (one work item's elements share z % ZB)
   G.zb_shift = 0;  // largest power of two <= 16 that divides nz / 8
   while (G.zb_shift < 4 && (G.nz / 8) % (2 << G.zb_shift) == 0) ++G.zb_shift;
-  s->lgx = plan_key(G.nx / 2);
+  s->lgx = plan_key(G.nx);
   s->lgy = plan_key(G.ny);
   s->lgz = plan_key(G.nz);
   const size_t cs = 2 * smi_elem_size(c);
@@ -1200,13 +1166,13 @@ int smi_pruned_create(smi_poisson* p) {
   SMI_CHECK_HIP(hipMalloc(&s->bufB, nB * cs));
   SMI_CHECK_HIP(hipMemsetAsync(s->bufB, 0, nB * cs, c->stream));
   SMI_DISPATCH(c, {
-    SMI_CHECK(upload_twiddles<T>(c, G.nx / 2, &s->tw[0]));
+    SMI_CHECK(upload_twiddles<T>(c, G.nx, &s->tw[0]));
     SMI_CHECK(upload_twiddles<T>(c, G.ny, &s->tw[1]));
     SMI_CHECK(upload_twiddles<T>(c, G.nz, &s->tw[2]));
   });
   // Green's table: full spectrum once through rocFFT, then fold / permute / normalise
   void* ghat = nullptr;
-  SMI_CHECK(smi_greens_spectrum_rocfft(c, G.nz, G.ny, G.nx, p->dx, p->x_range, &ghat));
+  SMI_CHECK(smi_greens_spectrum_shifted(c, G.nz, G.ny, G.nx, p->dx, p->x_range, &ghat));
   const int rc = fold_greens_table(c, s, ghat);
   hipFree(ghat);  // also when the fold failed
   return rc;

@@ -177,6 +177,63 @@ int smi_greens_spectrum_rocfft(smi_ctx* c, int gnz, int gny, int gnx, double dx_
   return 0;
 }
 
+// Green's function on the doubled node grid in y and z and on the first nx nodes in x, as the complex sequence
+// c_l g(z, y, l) exp(-i pi l / (2 nx)) with c_0 = 1, c_l = 2: the nx-point transform of that sequence along x is the
+// half-sample-shifted (odd-frequency) transform of the negacyclic extension of g at the frequencies 2 j + 1/2.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_greens_shifted(T* __restrict__ cplx, int n2z, int n2y, int nx, T dx,
+                                                           T two_yr, T two_zr) {
+  const long long total = (long long)n2z * n2y * nx;
+  SMI_GRID_STRIDE(i, total) {
+    int xx = (int)(i % nx);
+    long long r = i / nx;
+    int yy = (int)(r % n2y), zz = (int)(r / n2y);
+    T x = (T)((double)xx * (double)dx), y = (T)((double)yy * (double)dx), z = (T)((double)zz * (double)dx);
+    T yr = fmin(y, two_yr - y), zr = fmin(z, two_zr - z);
+    T dist = sqrt(x * x + yr * yr + zr * zr);
+    T v = (T(1) / dist) / (T)(4 * M_PI);
+    if (i == 0) v = T(1) / ((T)(4 * M_PI) * dx);
+    if (xx > 0) v *= T(2);
+    const double a = -M_PI * (double)xx / (2.0 * (double)nx);
+    cplx[2 * i] = v * (T)cos(a);
+    cplx[2 * i + 1] = v * (T)sin(a);
+  }
+}
+
+// Spectrum of the Green's function times dx^3 for the pruned back end: regular frequencies of the doubled grid in z
+// and y, half-sample-shifted frequencies 2 j + 1/2 (j = 0 .. nx - 1) of the 2 nx-point grid in x; complex
+// (2nz, 2ny, nx) in a fresh device buffer the caller frees.  Its real part is the multiplier (the imaginary part
+// belongs to the odd extension that a real, even kernel does not have).
+int smi_greens_spectrum_shifted(smi_ctx* c, int gnz, int gny, int gnx, double dx_d, double x_range, void** ghat_out) {
+  const int n2z = 2 * gnz, n2y = 2 * gny;
+  const long long ncplx = (long long)n2z * n2y * gnx;
+  const size_t es = smi_elem_size(c);
+  const bool f32 = c->dtype == SMI_F32;
+  void* ghat = nullptr;
+  hipfftHandle plan = 0;
+  SMI_CHECK_HIP(hipMalloc(&ghat, ncplx * 2 * es));
+  SMI_CHECK_FFT(hipfftPlan3d(&plan, n2z, n2y, gnx, f32 ? HIPFFT_C2C : HIPFFT_Z2Z));
+  SMI_CHECK_FFT(hipfftSetStream(plan, c->stream));
+  const double y_range = x_range * ((double)gny / gnx), z_range = x_range * ((double)gnz / gnx);
+  SMI_DISPATCH(c, {
+    T dx = (T)dx_d;
+    k_greens_shifted<T><<<blocks_for(ncplx), kBlock, 0, c->stream>>>((T*)ghat, n2z, n2y, gnx, dx, (T)(2 * y_range),
+                                                                    (T)(2 * z_range));
+    SMI_LAUNCH_CHECK();
+    if (f32)
+      SMI_CHECK_FFT(hipfftExecC2C(plan, (hipfftComplex*)ghat, (hipfftComplex*)ghat, HIPFFT_FORWARD));
+    else
+      SMI_CHECK_FFT(hipfftExecZ2Z(plan, (hipfftDoubleComplex*)ghat, (hipfftDoubleComplex*)ghat, HIPFFT_FORWARD));
+    T dx3 = dx * dx * dx;
+    k_scale<T><<<blocks_for(2 * ncplx), kBlock, 0, c->stream>>>((T*)ghat, 2 * ncplx, dx3);
+    SMI_LAUNCH_CHECK();
+  });
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  hipfftDestroy(plan);
+  *ghat_out = ghat;
+  return 0;
+}
+
 static int rocfft_destroy(smi_poisson* p) {
   RocfftState* s = p->rocfft;
   if (!s) return 0;

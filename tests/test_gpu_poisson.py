@@ -17,9 +17,9 @@ CODES = {"rocfft": 0, "pruned": 1}
 SHAPES = [((8, 8, 8), 2), ((16, 16, 16), 2), ((8, 16, 32), 1), ((32, 32, 32), 2), ((8, 12, 16), 2),
           # transform lengths 192, 384, 768 (radix 8 x R x 8 plans) on each axis
           ((8, 192, 384), 2), ((384, 8, 768), 2), ((8, 384, 16), 2), ((192, 8, 16), 2),
-          ((768, 8, 16), 2), ((8, 768, 16), 2), ((8, 8, 1536), 2),
+          ((768, 8, 16), 2), ((8, 768, 16), 2), ((8, 8, 768), 2),
           # the longest power-of-two plans
-          ((1024, 8, 16), 2), ((8, 2048, 16), 2), ((8, 8, 4096), 2),
+          ((1024, 8, 16), 2), ((8, 2048, 16), 2), ((8, 8, 2048), 2),
           # the benchmark's length on the z axis
           ((512, 8, 16), 2)]
 
@@ -88,7 +88,7 @@ def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("shape", [(8, 8, 1536), (8, 2048, 16), (768, 8, 16), (64, 64, 64), (8, 8, 512), (512, 8, 16)])
+@pytest.mark.parametrize("shape", [(8, 8, 768), (8, 8, 2048), (8, 2048, 16), (768, 8, 16), (64, 64, 64), (8, 8, 512), (512, 8, 16)])
 def test_poisson_single_precision_within_reference_rounding(smi, shape, backend):
     """How far a single-precision solve may be from the reference's, and why.  The reference builds the Green's
     function in real_t with r = min(x, 2 L - x) (UnboundedPoissonSolverMPI3D.py:102-106); in float32 the
