@@ -10,16 +10,21 @@
 //   and the first L outputs of a 2L-point inverse DFT are
 //       a[n] = IDFT_L(X[even])[n] + e^{+i pi n / L} IDFT_L(X[odd])[n].
 //
+// That is how the y and z axes are handled.  Along x, where the rows are real, the 2nx-point transform is taken at
+// the half-sample-shifted frequencies k + 1/2 instead: a real row then has exactly nx independent complex
+// coefficients (those at even k), all obtained from ONE nx-point transform of the row times e^{-i pi n / 2nx}, and
+// the Green's function enters through the shifted transform of its negacyclic extension (see k_fft_x_fwd).
+//
 // Five kernels per solve, all batched 1D FFTs held in LDS (one tile = TS sequences of L
 // points; Stockham radix-8/4/2 stages, eight points per work item in registers):
-//   x_fwd   real rows (read straight from the ghosted field) -> nx+1 complex per row
+//   x_fwd   real rows (read straight from the ghosted field) -> nx complex per row
 //   y_fwd   columns ny -> 2ny
 //   z_conv  columns nz -> 2nz, times the Green's spectrum, 2nz -> nz   (one kernel, in place)
 //   y_inv   columns 2ny -> ny
 //   x_inv   complex rows -> real rows written straight into the ghosted solution field
-// Spectral indices are stored split by parity ([even | odd]); the Green's table is laid out
-// in the same order, folded by its even symmetry and pre-multiplied by dx^3 and by the
-// backward normalisation, so it is real and (nz+1)(ny+1)(nx+1) in size.
+// The y and z spectral indices are stored split by parity ([even | odd]); the Green's table is laid out in the
+// same order, folded by its even symmetry in y and z and pre-multiplied by dx^3 and by the backward
+// normalisation, so it is real and (nz+1)(ny+1) nx in size.
 //
 // Slabs: after x_fwd each rank holds its z planes for all kx; one all-to-all hands every
 // rank a contiguous kx range for ALL z (before any y / z padding exists), y and z passes
@@ -304,13 +309,22 @@ constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per 
 #ifndef SMI_FFT_ZCOLS
 #define SMI_FFT_ZCOLS 0
 #endif
-// Row tiles one workgroup of the x kernels walks over (the twiddle set-up is then paid once for
-// all of them).  Measured: at 512^3 (256-point plan) two tiles take 7 % off x_inv and add 6 % to
-// x_fwd, four or more slow both down; at 384^3 (192-point mixed plan) two tiles cost x_inv 25 %;
-// at 256^3 nothing changes.  So: two tiles for x_inv on power-of-two plans of 256 points and more.
+// Row tiles one workgroup of the x kernels walks over (the twiddle set-up is then paid once for all of them) and
+// rows per tile.  Measured at 512^3 (512-point plan): two tiles against one take x_fwd from 0.95 to 0.93 ms and x_inv
+// from 0.98 to 0.94 ms; eight rows per tile instead of four change nothing.  The mixed plans keep one tile (two cost
+// the 192-point plan's x_inv a quarter when its rows were half as long).
+#ifndef SMI_FFT_XT_FWD
+#define SMI_FFT_XT_FWD 2
+#endif
+#ifndef SMI_FFT_XT_INV
+#define SMI_FFT_XT_INV 2
+#endif
+#ifndef SMI_FFT_XROWS
+#define SMI_FFT_XROWS 4
+#endif
 template <int LG>
 constexpr int x_tiles(bool fwd) {
-  return (!fwd && Plan<LG>::POW2 && LG >= 8) ? 2 : 1;
+  return fwd ? ((Plan<LG>::POW2 && LG >= 8) ? SMI_FFT_XT_FWD : 1) : ((Plan<LG>::POW2 && LG >= 8) ? SMI_FFT_XT_INV : 1);
 }
 #ifndef SMI_FFT_COLS_F32
 #define SMI_FFT_COLS_F32 16
@@ -318,7 +332,7 @@ constexpr int x_tiles(bool fwd) {
 // Sequences per tile.  Column passes want >= 16 (f32) / 8 (f64) so that every row of the tile
 // is a whole 128-byte line; TS * L / 8 threads, at most 1024.
 constexpr int tile_seqs(int L, int tps, bool f32, bool rows, int want_cols = 0) {
-  int want = rows ? 4 : (want_cols ? want_cols : (f32 ? SMI_FFT_COLS_F32 : 8));
+  int want = rows ? SMI_FFT_XROWS : (want_cols ? want_cols : (f32 ? SMI_FFT_COLS_F32 : 8));
   int ts = want;
   while (ts * L < 2048) ts *= 2;
   // double precision kernels hold twice the registers per lane: 512 lanes keep them out of scratch
@@ -548,9 +562,9 @@ constexpr size_t kLdsBudget = 128 * 1024;  // of 160 KB per CU
 //                            that neither a y tile (all ky' of one z) nor a z tile (all z of one
 //                            ky') strides over more than a few dozen pages
 //   green                  : [ky folded ny+1][kz folded nz+1][KXP]    real
-// KXL = spectral columns per rank (kx in parity-split order j = 0..nx, cut into P ranges),
+// KXL = spectral columns per rank (column j holds the shifted frequency 2 j + 1/2, j = 0..nx-1, cut into P ranges),
 // KXP = row pitch of bufB and of the Green's table (KXL rounded up to 16 columns: whole 128-byte
-// lines).  KXA = row pitch of the exchange buffers: KXP on one rank; across ranks KXL rounded up to
+// lines, plus one more tile where that would be a power-of-two pitch).  KXA = row pitch of the exchange buffers: KXP on one rank; across ranks KXL rounded up to
 // 64 bytes, because every pad column travels through both all-to-alls (19 % of their bytes at 8 ranks
 // with whole lines) while rows on arbitrary 8-byte offsets make the y kernels write scattered partial
 // lines (see smi_pruned_create).  The y kernels then read rows of bufT past their end (the
@@ -1185,15 +1199,6 @@ int smi_pruned_greens_download(smi_poisson* p, void* host) {
   return smi_memcpy_d2h(p->ctx, host, p->pruned->green, p->pruned->green_bytes);
 }
 
-// Narrow tiles for the column that is left over after the 16-column tiles of the y passes (nx + 1 = 32 x 16 + 1
-// spectral columns at 512^3).  A full tile for it transforms fifteen pad columns.  Measured at 512^3 on one GPU:
-// y_inv 2.00 -> 1.91 ms, y_fwd 1.98 -> 1.95 ms.  Only there: the narrow launch touches the same 128-byte lines as the
-// full tile it replaces (one 8-byte column per line), so it saves arithmetic, not traffic - nothing for the z
-// convolution, whose narrow launch took as long as the tile it replaced (122 against 118 us), and nothing across
-// ranks, where the narrow launches (80 - 120 us each whatever the rank count) would cost more than the one tile in
-// five they replace.
-constexpr int kNarrowCols = 4;
-
 template <typename T, int LG, int WC>
 static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int colbase, int ncols) {
   G.colbase = colbase;
@@ -1239,24 +1244,10 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
   PGeo G = s->G;
   G.nc = nc;
   G.c0 = c0;
-  constexpr int kMainZ = SMI_FFT_ZCOLS;
-  const int ts_main = which == 1 ? ZCfg<T, LG, kMainZ>::TS : TileCfg<T, LG, false, 0>::TS;
-  constexpr int ts_narrow = TileCfg<T, LG, false, kNarrowCols>::TS;
-  const int rest = G.KXL % ts_main;
-  static const bool no_narrow = getenv("SMI_FFT_NO_NARROW_TILES") != nullptr;
-  const bool split = !no_narrow && which != 1 && G.P == 1 && ts_narrow < ts_main && rest > 0 && rest <= ts_narrow &&
-                     G.KXL > ts_main;
   const int slot = which == 0 ? PROF_FFT_Y_FWD : (which == 1 ? PROF_FFT_Z_CONV : PROF_FFT_Y_INV);
   SmiProfScope prof(c, slot, (which == 1 ? 9.0 : 6.0) * nc * smi_S(c));
-  const int main_cols = split ? G.KXL - rest : G.KXL;
-  if (which == 1)
-    SMI_CHECK((launch_cols_tiles<T, LG, kMainZ>(c, s, which, G, 0, main_cols)));
-  else
-    SMI_CHECK((launch_cols_tiles<T, LG, 0>(c, s, which, G, 0, main_cols)));
-  if constexpr (kMainZ != kNarrowCols) {
-    if (split && which != 1) SMI_CHECK((launch_cols_tiles<T, LG, kNarrowCols>(c, s, which, G, main_cols, rest)));
-  }
-  return 0;
+  if (which == 1) return launch_cols_tiles<T, LG, SMI_FFT_ZCOLS>(c, s, which, G, 0, G.KXL);
+  return launch_cols_tiles<T, LG, 0>(c, s, which, G, 0, G.KXL);
 }
 
 template <typename T, int LG>

@@ -142,41 +142,6 @@ static int rocfft_create(smi_poisson* p) {
   return 0;
 }
 
-// Green's-function spectrum times dx^3 on the doubled grid, complex (2nz, 2ny, nx+1), in a
-// fresh device buffer the caller frees (used once by the pruned back end, which folds it).
-int smi_greens_spectrum_rocfft(smi_ctx* c, int gnz, int gny, int gnx, double dx_d, double x_range, void** ghat_out) {
-  const int n2z = 2 * gnz, n2y = 2 * gny, n2x = 2 * gnx;
-  const long long nreal = (long long)n2z * n2y * n2x, ncplx = (long long)n2z * n2y * (gnx + 1);
-  const size_t es = smi_elem_size(c);
-  const bool f32 = c->dtype == SMI_F32;
-  void* real_buf = nullptr;
-  void* ghat = nullptr;
-  hipfftHandle plan = 0;
-  SMI_CHECK_HIP(hipMalloc(&real_buf, nreal * es));
-  SMI_CHECK_HIP(hipMalloc(&ghat, ncplx * 2 * es));
-  SMI_CHECK_FFT(hipfftPlan3d(&plan, n2z, n2y, n2x, f32 ? HIPFFT_R2C : HIPFFT_D2Z));
-  SMI_CHECK_FFT(hipfftSetStream(plan, c->stream));
-  const double y_range = x_range * ((double)gny / gnx), z_range = x_range * ((double)gnz / gnx);
-  SMI_DISPATCH(c, {
-    T dx = (T)dx_d;
-    k_greens<T><<<blocks_for(nreal), kBlock, 0, c->stream>>>((T*)real_buf, n2z, n2y, n2x, dx, (T)(2 * x_range),
-                                                           (T)(2 * y_range), (T)(2 * z_range));
-    SMI_LAUNCH_CHECK();
-    if (f32)
-      SMI_CHECK_FFT(hipfftExecR2C(plan, (hipfftReal*)real_buf, (hipfftComplex*)ghat));
-    else
-      SMI_CHECK_FFT(hipfftExecD2Z(plan, (hipfftDoubleReal*)real_buf, (hipfftDoubleComplex*)ghat));
-    T dx3 = dx * dx * dx;
-    k_scale<T><<<blocks_for(2 * ncplx), kBlock, 0, c->stream>>>((T*)ghat, 2 * ncplx, dx3);
-    SMI_LAUNCH_CHECK();
-  });
-  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
-  hipfftDestroy(plan);
-  SMI_CHECK_HIP(hipFree(real_buf));
-  *ghat_out = ghat;
-  return 0;
-}
-
 // Green's function on the doubled node grid in y and z and on the first nx nodes in x, as the complex sequence
 // c_l g(z, y, l) exp(-i pi l / (2 nx)) with c_0 = 1, c_l = 2: the nx-point transform of that sequence along x is the
 // half-sample-shifted (odd-frequency) transform of the negacyclic extension of g at the frequencies 2 j + 1/2.
