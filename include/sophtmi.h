@@ -228,8 +228,8 @@ int smi_reduce_sum_sq(smi_ctx* ctx, const void* field, int ncomp, double* out);
 int smi_poisson_create(smi_poisson** out, smi_ctx* ctx, int global_nz, int global_ny, int global_nx,
                        double dx, double x_range, int backend);
 /* 1 when smi_poisson_create would accept this global grid on `nranks` slabs with this back end, else 0: the
- * rocFFT back end takes any grid on one rank; the pruned one needs nx / 2, ny and nz to be powers of two from 8
- * to 2048 or one of 192, 384, 768 (nx >= 16).  No counterpart in the reference (mpi4py-fft plans any size). */
+ * rocFFT back end takes any grid on one rank; the pruned one needs nx, ny and nz to be powers of two from 8
+ * to 2048 or one of 192, 384, 768.  No counterpart in the reference (mpi4py-fft plans any size). */
 int smi_poisson_supports(int global_nz, int global_ny, int global_nx, int nranks, int backend);
 int smi_poisson_destroy(smi_poisson* p);
 int smi_poisson_solve(smi_poisson* p, void* solution, const void* rhs);
