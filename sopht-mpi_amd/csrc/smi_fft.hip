@@ -919,7 +919,7 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
 // Lanes run along a row: a work item loads and stores its own eight elements directly (each a 256-byte or longer
 // contiguous run per row); the tile is only used by the transform stages.
 struct FieldGeo {
-  int g, px, vec2;  // vec2: rows start on an 8-byte boundary (kept for the callers; the kernels do not need it)
+  int g, px;
   long long plane, vol;
 };
 
@@ -1258,9 +1258,7 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, voi
   using Cfg = TileCfg<T, LG, true>;
   constexpr int TS = Cfg::TS, NT = Cfg::NT;
   const size_t lds_bytes = Cfg::BYTES;
-  // rows start g reals into a padded row: pairs are aligned when g and the row pitch are even
-  const int vec2 = (c->g % 2 == 0) && (c->px % 2 == 0) && ((uintptr_t)field % (2 * sizeof(T)) == 0);
-  FieldGeo F{c->g, c->px, vec2, (long long)c->plane, (long long)c->vol};
+  FieldGeo F{c->g, c->px, (long long)c->plane, (long long)c->vol};
   const int xt = x_tiles<LG>(fwd);
   dim3 grid((G.ny + TS * xt - 1) / (TS * xt), G.nzl, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[0];
