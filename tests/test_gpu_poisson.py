@@ -52,10 +52,40 @@ def _solver(smi, ctx, shape, x_range, real_t, backend):
     return h
 
 
-def _length_factor(shape):
-    """Round-off of both sides grows with the transform length (measured: 2.6e-8 per cell of the longest axis in
-    single precision on white noise, see test_poisson_single_precision_within_reference_rounding)."""
-    return 1.0 + 0.025 * max(shape)
+def _rounding_factor(shape, real_t, backend):
+    """Bound of the direct comparison with the oracle of the same precision, in units of TOL.
+
+    Double precision (TOL = 4e-15, about 18 units of round-off): on white noise both sides accumulate rounding
+    with the transform length; measured 0.3 (32 points) ... 2.5 (512) ... 9.5 (768 and 2048 points), the same
+    for both back ends.  Single precision, rocFFT back end (the reference's arithmetic restated literally,
+    Green's function included): measured <= 0.2 at every length but 8 x 192 x 384 (0.97).  The pruned back end
+    in single precision is not compared directly on white noise, see _assert_no_further_from_double."""
+    if np.dtype(real_t) == np.float64:
+        return 1.5 + max(shape) / 64.0
+    assert backend == "rocfft"
+    return 2.0
+
+
+def _assert_no_further_from_double(got, rhs, shape, g, x_range, what):
+    """Single precision, pruned back end.  The reference builds the Green's function in real_t with
+    r = min(x, 2 L - x) (UnboundedPoissonSolverMPI3D.py:102-106); in float32 that subtraction rounds by up to
+    2 L eps = 1.2e-7 L, which next to the mirrored singularity (r = dx) is a relative error of 2 nx eps of the
+    kernel: the mirrored half differs from the first half and the spectrum gets a small imaginary part.  The
+    pruned back end stores the spectrum of the exactly even kernel, folded and real.  On white noise the two
+    single-precision answers differ by up to 2.6e-8 per cell of the x axis, and the reference's own float32
+    answer is that far (or further) from the float64 one.  The bar: the GPU solve is no further from the
+    double-precision oracle than the single-precision oracle is."""
+    inner = (slice(g, -g),) * 3
+    ref32 = np.zeros_like(rhs)
+    UnboundedPoissonSolver3D(*shape, x_range=x_range, real_t=np.float32).solve(ref32, rhs, g)
+    ref64 = np.zeros(rhs.shape, dtype=np.float64)
+    UnboundedPoissonSolver3D(*shape, x_range=x_range, real_t=np.float64).solve(ref64, rhs.astype(np.float64), g)
+    scale = np.max(np.abs(ref64[inner]))
+    e_gpu = np.max(np.abs(got[inner].astype(np.float64) - ref64[inner])) / scale
+    e_ref = np.max(np.abs(ref32[inner] - ref64[inner])) / scale
+    print(f"{what} {shape}: gpu vs f64 {e_gpu:.2e}, reference f32 vs f64 {e_ref:.2e}")
+    assert e_gpu <= 1.25 * e_ref + 1e-6, (what, e_gpu, e_ref)
+    return ref32
 
 
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
@@ -74,30 +104,30 @@ def test_poisson_solve_matches_oracle(smi, shape, g, real_t, backend):
     oracle.vector_field_solve(want, rhs, g)
     got = dsol.get()
     inner = (slice(None),) + (slice(g, -g),) * 3
-    factor = _length_factor(shape)
-    assert_close(got[inner], want[inner], real_t, factor=factor, what=f"poisson[{backend}]")
+    if real_t == np.float32 and backend == "pruned":
+        for k in range(3):
+            _assert_no_further_from_double(got[k], rhs[k], shape, g, x_range, f"poisson[pruned] component {k}")
+        if max(shape) <= 64:  # short transforms: coordinate rounding and round-off stay below one TOL (0.2 - 0.4)
+            assert_close(got[inner], want[inner], real_t, factor=1.0, what="poisson[pruned], short axes")
+    else:
+        factor = _rounding_factor(shape, real_t, backend)
+        assert_close(got[inner], want[inner], real_t, factor=factor, what=f"poisson[{backend}]")
     mask = np.ones(got.shape, dtype=bool)
     mask[inner] = False
     assert np.array_equal(got[mask], sol0[mask]), "solution ghost cells were modified"
     assert np.array_equal(drhs.get(), rhs), "rhs was modified"
-    # scalar entry point, third component
+    # scalar entry point, third component: the same arithmetic as the vector call
     dsol1 = ctx.field()
     smi._lib.call("smi_poisson_solve", h, dsol1.ptr, drhs[2].ptr)
-    assert_close(dsol1.get()[inner[1:]], want[2][inner[1:]], real_t, factor=factor, what="scalar solve")
+    assert_close(dsol1.get()[inner[1:]], got[2][inner[1:]], real_t, factor=0.5, what="scalar solve vs vector solve")
     smi._lib.call("smi_poisson_destroy", h)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("shape", [(8, 8, 768), (8, 8, 2048), (8, 2048, 16), (768, 8, 16), (64, 64, 64), (8, 8, 512), (512, 8, 16)])
 def test_poisson_single_precision_within_reference_rounding(smi, shape, backend):
-    """How far a single-precision solve may be from the reference's, and why.  The reference builds the Green's
-    function in real_t with r = min(x, 2 L - x) (UnboundedPoissonSolverMPI3D.py:102-106); in float32 the
-    subtraction rounds, the mirrored half of the kernel differs from the first half by up to 2.4e-4 (1536 cells),
-    and the spectrum gets a small imaginary part.  The rocFFT back end carries that along (it restates the
-    reference literally); the pruned back end stores the spectrum folded by the symmetry the exact kernel has, i.e.
-    keeps the real part.  On white noise the two single-precision answers then differ by up to 2.6e-8 per cell of
-    the longest axis - and the reference's own float32 answer is that far (or further) from the float64 one.  The
-    bar: the GPU solve is no further from the double-precision oracle than the single-precision oracle is."""
+    """Scalar solves at the longest transform lengths of every axis, both back ends: no further from the
+    double-precision oracle than the single-precision oracle is (see _assert_no_further_from_double)."""
     g, x_range = 2, 1.3
     rng = np.random.default_rng(7)
     ctx = make_ctx(smi, shape, g, np.float32)
@@ -105,17 +135,7 @@ def test_poisson_single_precision_within_reference_rounding(smi, shape, backend)
     rhs = rand_field(rng, ctx.padded_shape, np.float32)
     drhs, dsol = ctx.from_numpy(rhs), ctx.field()
     smi._lib.call("smi_poisson_solve", h, dsol.ptr, drhs.ptr)
-    inner = (slice(g, -g),) * 3
-    got = dsol.get()[inner].astype(np.float64)
-    ref32 = np.zeros_like(rhs)
-    UnboundedPoissonSolver3D(*shape, x_range=x_range, real_t=np.float32).solve(ref32, rhs, g)
-    ref64 = np.zeros(rhs.shape, dtype=np.float64)
-    UnboundedPoissonSolver3D(*shape, x_range=x_range, real_t=np.float64).solve(ref64, rhs.astype(np.float64), g)
-    scale = np.max(np.abs(ref64[inner]))
-    e_gpu = np.max(np.abs(got - ref64[inner])) / scale
-    e_ref = np.max(np.abs(ref32[inner] - ref64[inner])) / scale
-    print(f"{shape} {backend}: gpu vs f64 {e_gpu:.2e}, reference f32 vs f64 {e_ref:.2e}")
-    assert e_gpu <= 1.25 * e_ref + 1e-6, (e_gpu, e_ref)
+    _assert_no_further_from_double(dsol.get(), rhs, shape, g, x_range, backend)
     smi._lib.call("smi_poisson_destroy", h)
 
 
