@@ -61,6 +61,13 @@ int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx,
                    int rank, int nranks);
 int smi_ctx_destroy(smi_ctx* ctx);
 int smi_sync(smi_ctx* ctx);
+/* Execution switches of a context (no counterpart in the reference; tests and measurements).  smi_ctx_create reads
+ * them once from the environment and no entry point consults the environment afterwards:
+ *   "no_fused_advect_diffuse" (SMI_NO_FUSED_ADVECT_DIFFUSE)  1: advection and diffusion as two passes
+ *   "fused_split_launch"      (SMI_FUSED_SPLIT_LAUNCH)       1: interior z chunks and outer z chunks as two launches
+ *   "fused_zchunk"            (SMI_FUSED_ZCHUNK)             planes per workgroup of the one-pass kernel, 0 = automatic
+ *   "transpose_chunks"        (SMI_FFT_TRANSPOSE_CHUNKS)     1, 2 or 4 z chunks per spectral transpose across ranks */
+int smi_ctx_set_option(smi_ctx* ctx, const char* name, int value);
 
 /* RCCL communicator over the slab ranks.  unique_id: the 128-byte ncclUniqueId made
  * by smi_comm_unique_id on rank 0 and broadcast by the host launcher.  Replaces
@@ -178,9 +185,10 @@ int smi_rotational_advection_update(smi_ctx* ctx, void* out, void* velocity, voi
 /* The advection and the diffusion of rotational_form_navier_stokes_timestep (flow_simulators_mpi_3d.py:395-411:
  * cross product, vorticity update with dt / (2 dx), vector diffusion timestep with nu dt / dx^2), written to another
  * array: out = w* + c lap7(w*) where the diffusion flux is not zeroed, w* elsewhere, w* = the result of
- * smi_rotational_advection_update.  One pass over the arrays where the context allows it (single rank, single
- * precision, 16-byte aligned rows), otherwise the two operators through `scratch` (a vector field).  No array may
- * alias another. */
+ * smi_rotational_advection_update.  One pass over the arrays where the context allows it (one rank or z-slabs with
+ * at least two ghost layers, 16-byte aligned rows; across slabs one exchange of both ghost planes of velocity and
+ * vorticity runs beside the interior chunks), otherwise - pencils, unaligned rows - the two operators through
+ * `scratch` (a vector field).  No array may alias another. */
 int smi_advection_diffusion_update(smi_ctx* ctx, void* out, void* velocity, void* vorticity, void* scratch,
                                    double prefactor, double nu_dt_by_dx2);
 /* gen_curl_pyst_mpi_kernel_3d, curl_mpi_3d.py:10-196 */
@@ -342,8 +350,8 @@ int smi_flow_step_ns3d(smi_ctx* ctx, smi_poisson* p, void* vorticity, void* velo
  * arrays of flow_simulators_mpi_3d.py:191-194; the reference treats buffer_vector as scratch).  Advection and
  * diffusion (:395-411) then run as ONE pass from `vorticity` into `buffer_vector` and the rest of the step works on
  * `buffer_vector`.  *result_in_buffer = 1: the new vorticity is in `buffer_vector`, `vorticity` holds scratch;
- * 0: the result is in `vorticity`, as with smi_flow_step_ns3d (several ranks, double precision, filter settings
- * that need the buffer). */
+ * 0: the result is in `vorticity`, as with smi_flow_step_ns3d (unaligned rows, one ghost layer across slabs, filter
+ * settings that need the buffer).  z-slabs are served like a single rank. */
 int smi_flow_step_ns3d_swap(smi_ctx* ctx, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
                             void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu, double dx,
                             int penalty_width, const double* fac_lo, const double* fac_hi, const double* free_stream,

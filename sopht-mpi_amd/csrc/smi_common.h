@@ -60,6 +60,13 @@ struct smi_ctx {
   double umax_band;
   const void* umax_field;  // the velocity array that maximum belongs to
   int ordered_spread;      // smi_set_ordered_spread: Lagrangian -> Eulerian spreading adds nodes in index order
+  // Switches of the one-pass advection + diffusion kernel, read from the environment ONCE when the context is
+  // created (SMI_NO_FUSED_ADVECT_DIFFUSE, SMI_FUSED_SPLIT_LAUNCH, SMI_FUSED_ZCHUNK) and changed afterwards only
+  // through smi_ctx_set_option: no_fused = run the two-pass form; split_launch = the two launches of the overlapped
+  // multi-rank schedule on a single rank; fused_zchunk = planes per workgroup (0: chosen from the grid).
+  int opt_no_fused, opt_split_launch, opt_fused_zchunk;
+  // z chunks each spectral transpose of a multi-rank Poisson solve is cut into (SMI_FFT_TRANSPOSE_CHUNKS, 1 / 2 / 4)
+  int opt_transpose_chunks;
 };
 constexpr int kUmaxSlots = 64;
 

@@ -1,4 +1,6 @@
 // Context, memory, elementwise operators and reductions of libsophtmi (gfx950).
+#include <cstdlib>
+
 #include "smi_common.h"
 #include "smi_prof.h"
 
@@ -79,6 +81,16 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
     c->phys_ylo = rank == 0;
     c->phys_yhi = rank == nranks - 1;
   }
+  // environment switches are read here, once, and never on the step path
+  c->opt_no_fused = getenv("SMI_NO_FUSED_ADVECT_DIFFUSE") != nullptr;
+  c->opt_split_launch = getenv("SMI_FUSED_SPLIT_LAUNCH") != nullptr;
+  if (const char* e = getenv("SMI_FUSED_ZCHUNK")) c->opt_fused_zchunk = atoi(e) > 0 ? atoi(e) : 32;
+  c->opt_transpose_chunks = 1;
+  if (const char* e = getenv("SMI_FFT_TRANSPOSE_CHUNKS")) {
+    const int n = atoi(e);
+    SMI_REQUIRE(n == 1 || n == 2 || n == 4, "SMI_FFT_TRANSPOSE_CHUNKS=%s: must be 1, 2 or 4", e);
+    c->opt_transpose_chunks = n;
+  }
   // staging for the ghost sum (and the host-staged plane upload): 3 components of g planes
   c->halo_cap = (size_t)3 * ghost * c->plane * smi_elem_size(c);
   const int rc = ctx_allocate(c);
@@ -87,6 +99,26 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
     return rc;
   }
   *out = c;
+  return 0;
+}
+
+// Changes one of the switches smi_ctx_create read from the environment (tests, measurements).
+extern "C" int smi_ctx_set_option(smi_ctx* c, const char* name, int value) {
+  SMI_REQUIRE(c && name, "smi_ctx_set_option: null argument");
+  if (!strcmp(name, "no_fused_advect_diffuse")) {
+    c->opt_no_fused = value != 0;
+  } else if (!strcmp(name, "fused_split_launch")) {
+    c->opt_split_launch = value != 0;
+  } else if (!strcmp(name, "fused_zchunk")) {
+    SMI_REQUIRE(value >= 0, "smi_ctx_set_option: fused_zchunk %d must not be negative", value);
+    c->opt_fused_zchunk = value;
+  } else if (!strcmp(name, "transpose_chunks")) {
+    SMI_REQUIRE(value == 1 || value == 2 || value == 4, "smi_ctx_set_option: transpose_chunks %d must be 1, 2 or 4",
+                value);
+    c->opt_transpose_chunks = value;
+  } else {
+    SMI_REQUIRE(false, "smi_ctx_set_option: unknown option '%s'", name);
+  }
   return 0;
 }
 

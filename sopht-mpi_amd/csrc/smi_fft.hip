@@ -383,12 +383,7 @@ template <int SIGN, bool FIRST_FROM_LDS, int LG, typename LAY, int S, typename T
 __device__ __forceinline__ void fft_run_from(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u,
                                              const Twiddles<T, LG>& tw) {
   if constexpr (S < Plan<LG>::NST) {
-#ifdef SMI_EXP_NO_EXCHANGE
-    // timing experiment only (wrong results): the stages without their LDS exchanges and barriers
-    if constexpr (false) {
-#else
     if constexpr (S > 0 || FIRST_FROM_LDS) {
-#endif
       if constexpr (S > 0) {
         Cx<T>* w = sel.next();
 #pragma unroll
@@ -828,15 +823,8 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
   const T* gbase = green + (size_t)kyc * (G.nz + 1) * G.KXP;  // all kz of this ky are contiguous rows
   Cx<T> v[8], res[8], a0[8];
   Cx<T>* base = tile_base(0);
-  // timing experiments only (wrong results): the arithmetic and the exchanges without the column loads and / or stores
-#if defined(SMI_EXP_NO_GLOBAL) || defined(SMI_EXP_NO_LOAD)
-#define SMI_Z_LOAD(p) (Cx<T>{wu.x + (T)(m), wu.y})
-#else
-#define SMI_Z_LOAD(p) stream_load(p)
-#endif
-
 #pragma unroll
-  for (int m = 0; m < 8; ++m) a0[m] = ok ? SMI_Z_LOAD(&(base + m * mstep)[off]) : Cx<T>{0, 0};
+  for (int m = 0; m < 8; ++m) a0[m] = ok ? stream_load(&(base + m * mstep)[off]) : Cx<T>{0, 0};
   for (int it = 0; it < ntile; ++it) {
     Cx<T>* next = tile_base(it + 1 < ntile ? it + 1 : it);
 #pragma unroll
@@ -845,7 +833,7 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
       for (int m = 0; m < 8; ++m) v[m] = pz ? a0[m] * mul_c16(wu, m) : a0[m];
       if (!LEAN && pz == 1 && it + 1 < ntile) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) a0[m] = ok ? SMI_Z_LOAD(&(next + m * mstep)[off]) : Cx<T>{0, 0};
+        for (int m = 0; m < 8; ++m) a0[m] = ok ? stream_load(&(next + m * mstep)[off]) : Cx<T>{0, 0};
       }
       // Green's table values for the spectrum at kz = 2 z + pz: all eight loads are issued
       // before the transform so that their latency hides behind it
@@ -862,43 +850,24 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
                             : gbase + (size_t)(2 * L - 2 * m * L8 - 2 * L8 + 1) * G.KXP;
         gval[m] = ok ? gm[m < 4 ? goff_lo : goff_hi] : T(0);
       }
-#ifndef SMI_EXP_NO_FFT  // timing experiment only (wrong results): the kernel's loads and stores without its transforms
       fft_run<-1, false, LG, Lay>(v, sel, t, u, tw);
-#endif
       // the transform leaves element u + m L/8 in v[m], which is exactly what the first stage
       // of the inverse wants from this work item: scale in registers and go straight on
 #pragma unroll
       for (int m = 0; m < 8; ++m) v[m] = scale(v[m], gval[m]);
       if (LEAN && pz == 1 && it + 1 < ntile) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) a0[m] = ok ? SMI_Z_LOAD(&(next + m * mstep)[off]) : Cx<T>{0, 0};
+        for (int m = 0; m < 8; ++m) a0[m] = ok ? stream_load(&(next + m * mstep)[off]) : Cx<T>{0, 0};
       }
-#ifndef SMI_EXP_NO_FFT
       fft_run<+1, false, LG, Lay>(v, sel, t, u, tw);
-#endif
       if (pz == 0) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) res[m] = v[m];
       } else {
-#if defined(SMI_EXP_NO_GLOBAL) || defined(SMI_EXP_NO_STORE)
-        // timing experiments: every output is formed and folded into the (never true) store condition, so that none
-        // of the arithmetic is dead
-        Cx<T> acc{0, 0};
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          v[m] = res[m] + conj(mul_c16(wu, m)) * v[m];
-          acc = acc + v[m];
-        }
-        if (ok && acc.x == (T)123456.75 && acc.y == (T)-3.5) {
-#pragma unroll
-          for (int m = 0; m < 8; ++m) stream_store(&(base + m * mstep)[off], v[m]);
-        }
-#else
         if (ok) {
 #pragma unroll
           for (int m = 0; m < 8; ++m) stream_store(&(base + m * mstep)[off], res[m] + conj(mul_c16(wu, m)) * v[m]);
         }
-#endif
       }
     }
     base = next;

@@ -254,8 +254,10 @@ __global__ void __launch_bounds__(256) k_ib_spread_fused(T* __restrict__ eul, co
 // (EulerianLagrangianGridCommunicatorMPI3D.py:404-425: field[window] += force * weights, one node after the other),
 // so overlapping windows accumulate in node order with one rounding to the field type per node and the result does
 // not depend on how the hardware schedules atomics.  The loads and stores are device-scope atomic accesses (they
-// bypass the per-CU cache); the wave issues them in program order, and accesses to one address reach the same L2
-// channel in that order.  A few microseconds per node: for parity runs, not for production.
+// bypass the per-CU cache).  Windows of consecutive nodes overlap, so one lane's load for node n + 1 may hit the
+// address another lane stored for node n: a wavefront-scope fence at the top of every iteration makes the wave wait
+// until the stores of the previous node have been acknowledged before it issues the next loads.  A few microseconds
+// per node: for parity runs, not for production.
 // WEIGHTS: materialised weights / index arrays (smi_ib_spread) instead of positions (smi_ib_spread_fused).
 template <typename T, bool WEIGHTS>
 __global__ void __launch_bounds__(64) k_ib_spread_ordered(T* __restrict__ eul, const double* __restrict__ forcing,
@@ -266,6 +268,7 @@ __global__ void __launch_bounds__(64) k_ib_spread_ordered(T* __restrict__ eul, c
   const int c = blockIdx.x, lane = threadIdx.x;
   T* field = eul + (long long)c * G.vol;
   for (long long node = 0; node < m; ++node) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     long long ix, iy, iz;
     double w;
     if (WEIGHTS) {

@@ -1553,7 +1553,7 @@ static int fused_zchunk(const smi_ctx* c, int tiles_per_plane) {
   static int cus[64] = {};
   int& n_cu = cus[c->device & 63];
   if (n_cu == 0 && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
-  if (const char* e = getenv("SMI_FUSED_ZCHUNK")) return atoi(e) > 0 ? atoi(e) : 32;
+  if (c->opt_fused_zchunk > 0) return c->opt_fused_zchunk;
   int best = c->pz;
   double best_eff = 0.0;
   for (int n = 1; n * 8 <= c->pz; ++n) {
@@ -1582,7 +1582,7 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
                             int* ran) {
   *ran = 0;
   SMI_REQUIRE(out != velocity && out != vorticity, "advection-diffusion: output and input must not alias");
-  if (c->dtype != SMI_F32 || getenv("SMI_NO_FUSED_ADVECT_DIFFUSE")) return 0;
+  if (c->dtype != SMI_F32 || c->opt_no_fused) return 0;
   if (smi_multi_rank(c) && c->g < 2) return 0;
   // across an inner y face the advected vorticity of the neighbour's edge row would have to be formed here as it
   // is for z (Geo::za_lo); a pencil runs the two operators one after the other instead
@@ -1604,10 +1604,10 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   };
   if (!smi_multi_rank(c)) {
     SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
-    // SMI_FUSED_SPLIT_LAUNCH: the two launches of the overlapped multi-rank schedule below (interior chunks, then the
+    // split_launch (SMI_FUSED_SPLIT_LAUNCH, smi_ctx_set_option): the two launches of the overlapped multi-rank schedule below (interior chunks, then the
     // first and the last chunk) without the exchange between them - a single GPU can then check that they cover the
     // array exactly like the one launch
-    if (getenv("SMI_FUSED_SPLIT_LAUNCH") && nchunks >= 3) {
+    if (c->opt_split_launch && nchunks >= 3) {
       launch(1, 1, nchunks - 2);
       launch(0, nchunks - 1, 2);
     } else {

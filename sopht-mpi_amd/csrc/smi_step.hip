@@ -16,9 +16,9 @@ static int flow_step(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity
                      void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu, double dx,
                      int penalty_width, const double* fac_lo, const double* fac_hi, const double* free_stream,
                      int filter_order, int filter_type, int* result_in_buffer) {
-  SMI_REQUIRE(c && c->nranks_y == 1,
-              "the one-call flow step serves z-slabs; a pencil decomposition runs the operators one by one");
   SMI_REQUIRE(c, "smi_flow_step_ns3d: null context");
+  SMI_REQUIRE(c->nranks_y == 1,
+              "the one-call flow step serves z-slabs; a pencil decomposition runs the operators one by one");
   const int saved = c->halo_depth;
   const bool shallow = filter_order == 0 || (filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE);
   if (shallow) c->halo_depth = 1;

@@ -428,7 +428,7 @@ class VirtualBoundaryForcingMPI:
             return
         extent = comm.eul_subblock_dx[::-1] * np.asarray(self.mpi_construct.grid_topology)[::-1]   # x, y, z
         lo, hi = nodes.lo - comm.eul_grid_coord_shift, nodes.hi - comm.eul_grid_coord_shift
-        if np.all(hi < extent) and lo[2] >= 0:
+        if np.all(hi < extent) and np.all(lo >= 0):
             return
         comm._compute_lag_nodes_rank_address(self.local_lag_grid_position_field.get())
 

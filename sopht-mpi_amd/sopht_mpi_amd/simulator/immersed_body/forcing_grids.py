@@ -83,9 +83,14 @@ class FramedForcingGrid(ImmersedBodyForcingGrid):
 
     # ---- the arrays the reference's users read ---------------------------------
     def _host_field(self, name):
+        """Host copy of a node array; while the device forms the nodes (update_device_nodes) the positions, the
+        velocities AND the moment arms are brought up to date first, so that the host-side
+        transfer_forcing_from_grid_to_body sees the arms of the body's current pose."""
         if self._host_stale and self._dev is not None:
             self._position_field[...] = self._dev["pos"].get()
             self._velocity_field[...] = self._dev["vel"].get()
+            if getattr(self, "_arm_field", None) is not None:
+                self._arm_field[...] = self._dev["arms"].get()
             self._host_stale = False
         return getattr(self, name)
 
@@ -93,6 +98,9 @@ class FramedForcingGrid(ImmersedBodyForcingGrid):
                               lambda self, v: setattr(self, "_position_field", v))
     velocity_field = property(lambda self: self._host_field("_velocity_field"),
                               lambda self, v: setattr(self, "_velocity_field", v))
+    # lab-frame offset of every node from the centre of its frame; the subclasses expose it under the name their
+    # sopht counterpart uses (global_frame_relative_position_field, moment_arm)
+    _arm_field = None
 
     # ---- what a subclass states -------------------------------------------------
     def frames(self):
@@ -163,10 +171,12 @@ class SphereForcingGrid(FramedForcingGrid):
         self.local_frame_relative_position_field = self.sphere.radius * np.concatenate(local, axis=1)
         super().__init__(grid_dim=grid_dim, num_lag_nodes=self.local_frame_relative_position_field.shape[1])
         self._init_frames(np.zeros(self.num_lag_nodes, dtype=np.int32), self.local_frame_relative_position_field, 1)
-        self.global_frame_relative_position_field = np.zeros_like(self.position_field)
+        self._arm_field = np.zeros_like(self.position_field)
         self._spacing = 2 * np.pi * self.sphere.radius / n_eq
         self.compute_lag_grid_position_field()
         self.compute_lag_grid_velocity_field()
+
+    global_frame_relative_position_field = property(lambda self: self._host_field("_arm_field"))
 
     def compute_lag_grid_position_field(self):
         q = self.sphere.director_collection[:, :, 0]
@@ -243,11 +253,13 @@ class CosseratRodSurfaceForcingGrid(FramedForcingGrid):
         self.local_frame_surface_points = np.stack([np.cos(angles), np.sin(angles), np.zeros_like(angles)])
         super().__init__(grid_dim=grid_dim, num_lag_nodes=int(self.surface_grid_points.sum()))
         self._init_frames(self.element_of_node, self.local_frame_surface_points, n)
-        self.moment_arm = np.zeros_like(self.position_field)
+        self._arm_field = np.zeros_like(self.position_field)
         self.with_cap = with_cap
         self._density = surface_grid_density_for_largest_element
         self.compute_lag_grid_position_field()
         self.compute_lag_grid_velocity_field()
+
+    moment_arm = property(lambda self: self._host_field("_arm_field"))
 
     def compute_lag_grid_position_field(self):
         rod, e = self.cosserat_rod, self.element_of_node

@@ -291,7 +291,8 @@ class MPILagrangianFieldCommunicator3D:
         cz = ((global_lag_positions[2, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[0]).astype(np.int32)
         cy = ((global_lag_positions[1, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[1]).astype(np.int32)
         cx = ((global_lag_positions[0, ...] - self.eul_grid_coord_shift) / self.eul_subblock_dx[2]).astype(np.int32)
-        if np.any(cx >= topo[2]) or np.any(cy >= topo[1]) or np.any(cz >= topo[0]) or np.any(cz < 0):
+        if (np.any(cx >= topo[2]) or np.any(cy >= topo[1]) or np.any(cz >= topo[0])
+                or np.any(cz < 0) or np.any(cy < 0) or np.any(cx < 0)):
             logger.error("Lagrangian node is found outside of Eulerian domain!")
             raise RuntimeError("Lagrangian node is found outside of Eulerian domain!")
         return (cz * int(topo[1]) + cy).astype(np.int32)   # Cartesian rank of block (cz, cy)

@@ -142,6 +142,12 @@ def test_lagrangian_owner_map(smi):
     cz = ((pos[2] - shift) / (dx * 8)).astype(np.int32)
     cy = ((pos[1] - shift) / (dx * 4)).astype(np.int32)
     assert np.array_equal(commp.rank_address, cz * 2 + cy) and set(commp.rank_address.tolist()) == {0, 1, 2, 3}
+    # a node a whole block below the y or the x face must not alias a valid rank
+    for axis, value in ((1, -0.6), (0, -1.2), (2, -1.1)):
+        bad = pos.copy()
+        bad[axis, 5] = value
+        with pytest.raises(RuntimeError):
+            commp.map_lagrangian_nodes_based_on_position(bad)
 
 
 def test_2d_lagrangian_and_field_communicators(smi):

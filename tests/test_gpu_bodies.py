@@ -183,11 +183,23 @@ def test_nodes_formed_on_the_device_match_the_host_grid(smi, body, monkeypatch):
     rng = np.random.default_rng(22)
     host, f_host = make(host=True)
     assert dev.nodes_on_device and not host.nodes_on_device
+    turn = np.array([[1.0, 0.0, 0.0], [0.0, np.cos(0.3), np.sin(0.3)], [0.0, -np.sin(0.3), np.cos(0.3)]])
     for cycle in range(2):
         for it in (dev, host):
+            # the body moves and turns between the cycles: node arrays and moment arms must follow its pose
+            moving = getattr(it.forcing_grid, "sphere", None) or it.forcing_grid.cosserat_rod
+            moving.director_collection[...] = np.einsum("ij,jkn->ikn", turn, moving.director_collection)
+            moving.position_collection[0] += 0.01
             it.compute_flow_forces_and_torques()
             it.time_step(1e-3)
             it()
+        # the reference-style host transfer of the device interactor's node forces uses the arms of the CURRENT pose
+        dev.compute_flow_forces_and_torques()
+        f_host, t_host = np.zeros_like(dev.body_flow_forces), np.zeros_like(dev.body_flow_torques)
+        dev.forcing_grid.transfer_forcing_from_grid_to_body(f_host, t_host, dev.global_lag_grid_forcing_field)
+        assert_close(f_host, dev.body_flow_forces, np.float64, factor=1e3, what="host transfer of device forces")
+        assert_close(t_host, dev.body_flow_torques, np.float64, factor=1e3, what="host transfer of device torques")
+        host.compute_flow_forces_and_torques()
         gd, gh = dev.forcing_grid, host.forcing_grid
         scale = np.abs(gh.position_field).max()
         assert np.abs(gd.position_field - gh.position_field).max() <= 4e-16 * scale

@@ -94,8 +94,8 @@ def _single_and_slabs(worker_name, n, steps, nranks, port, out_dir, extra_env=No
 
 @pytest.mark.parametrize("n,nranks", [(512, 8), (512, 4), (512, 2)])
 def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, nranks):
-    """The scaling configuration itself - the 512^3 benchmark workload cut into 8 z-slabs of 64 planes, 65 spectral
-    columns per rank in rows of 72 - run over the RCCL branches for two steps and compared with the single-rank run
+    """The scaling configuration itself - the 512^3 benchmark workload cut into 8 z-slabs of 64 planes, 64 spectral
+    columns per rank in rows of 512 bytes - run over the RCCL branches for two steps and compared with the single-rank run
     of the same workload: time step, maximum vorticity, divergence norm, and the sum of every interior plane of the
     vorticity and of |velocity| (a slab boundary that went wrong shows in the planes next to it)."""
     import json

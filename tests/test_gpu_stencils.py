@@ -303,14 +303,14 @@ def test_tiled_kernels_on_random_shapes(smi, shape, g):
                                      ((16, 16, 34), 3), ((50, 21, 512), 2)])
 def test_fused_advection_diffusion_shapes(smi, shape, g, zchunk, monkeypatch):
     """The one-pass advection + diffusion kernel (single precision) on grids with one to several tiles per plane,
-    partial tiles in both directions and, through SMI_FUSED_ZCHUNK, one to several z chunks with partial last
+    partial tiles in both directions and, through the fused_zchunk option, one to several z chunks with partial last
     chunks: against the reference's operator sequence (cross product, vorticity update, diffusion timestep)
     on the whole array, ghost cells included, and against the two-pass path of the library bit for bit."""
     real_t = np.float32
-    if zchunk is not None:
-        monkeypatch.setenv("SMI_FUSED_ZCHUNK", zchunk)
     rng = np.random.default_rng(sum(shape))
     ctx = make_ctx(smi, shape, g, real_t)
+    if zchunk is not None:
+        _call(smi, "smi_ctx_set_option", ctx.handle, b"fused_zchunk", int(zchunk))
     assert ctx.padded_shape[2] % 4 == 0
     u = rand_field(rng, (3,) + ctx.padded_shape, real_t)
     w = rand_field(rng, (3,) + ctx.padded_shape, real_t)
@@ -326,14 +326,14 @@ def test_fused_advection_diffusion_shapes(smi, shape, g, zchunk, monkeypatch):
     st.vector_diffusion_timestep(want, np.zeros(ctx.padded_shape, dtype=real_t), c, g)
     assert_close(dout.get(), want, real_t, factor=2.0, what="advection + diffusion, one pass")
     # the two-pass path of the library: same arithmetic in the same order
-    monkeypatch.setenv("SMI_NO_FUSED_ADVECT_DIFFUSE", "1")
+    _call(smi, "smi_ctx_set_option", ctx.handle, b"no_fused_advect_diffuse", 1)
     dout2 = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
     _call(smi, "smi_advection_diffusion_update", ctx.handle, dout2.ptr, du.ptr, dw.ptr, dscr.ptr, float(p), float(c))
     assert np.array_equal(dout.get(), dout2.get()), "one pass and two passes must agree bit for bit"
     assert np.array_equal(du.get(), u) and np.array_equal(dw.get(), w), "inputs were modified"
     # the launch schedule of the overlapped multi-rank path (interior chunks first, then the two outer chunks)
-    monkeypatch.delenv("SMI_NO_FUSED_ADVECT_DIFFUSE")
-    monkeypatch.setenv("SMI_FUSED_SPLIT_LAUNCH", "1")
+    _call(smi, "smi_ctx_set_option", ctx.handle, b"no_fused_advect_diffuse", 0)
+    _call(smi, "smi_ctx_set_option", ctx.handle, b"fused_split_launch", 1)
     dout3 = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
     _call(smi, "smi_advection_diffusion_update", ctx.handle, dout3.ptr, du.ptr, dw.ptr, dscr.ptr, float(p), float(c))
     assert np.array_equal(dout.get(), dout3.get()), "split launches must cover the array like the single launch"

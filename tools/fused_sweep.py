@@ -1,4 +1,4 @@
-"""Times the one-pass advection + diffusion kernel at 512^3 for several z chunk lengths (SMI_FUSED_ZCHUNK).
+"""Times the one-pass advection + diffusion kernel at 512^3 for several z chunk lengths (the fused_zchunk option).
   python tools/fused_sweep.py [grid] [chunk ...]"""
 import os
 import sys
@@ -18,10 +18,7 @@ u, w, out, scr = (ctx.field(3) for _ in range(4))
 for f in (u, w):
     f[0] = ctx.from_numpy(rng.random(ctx.padded_shape, dtype=np.float32))
 for c in chunks:
-    if c == "auto":
-        os.environ.pop("SMI_FUSED_ZCHUNK", None)
-    else:
-        os.environ["SMI_FUSED_ZCHUNK"] = c
+    _lib.call("smi_ctx_set_option", ctx.handle, b"fused_zchunk", 0 if c == "auto" else int(c))
     for rep in range(2):
         _lib.call("smi_prof_enable", ctx.handle, 1)
         _lib.call("smi_prof_reset", ctx.handle)
