@@ -3,15 +3,19 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-N = 1: 512^3 navier_stokes step on one MI355X (grid-point updates per second of a flow step).  N > 1 (launched by
-torch.distributed.run, one rank per GPU): the same 512^3 grid cut into N z-slabs (strong
-scaling: total work fixed).  Prints ONE JSON line on rank 0.
+N = 1: 512^3 navier_stokes step on one MI355X (grid-point updates per second of a flow step).  N > 1, one rank per
+GPU: the same 512^3 grid cut into N z-slabs (strong scaling: total work fixed).  The ranks are either started from
+outside (torch.distributed.run sets RANK / WORLD_SIZE / MASTER_*) or, when `python bench.py --gpus N` is run by
+itself, by this script: it then starts torch.distributed.run as a child process before touching the GPU, relays
+rank 0's line and leaves with the child's status.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -143,6 +147,35 @@ def cpu_baseline(grid, steps, warmup):
     }
 
 
+def launch_ranks(n_gpus, argv, timeout_s):
+    """`python bench.py --gpus N` without a launcher around it: start the N rank processes (torch.distributed.run,
+    one per GPU, rendezvous on 127.0.0.1) as a CHILD process - nothing in this process has touched the GPU - pass its
+    output through and return its exit status.  A child that outlives `timeout_s` is ended with its process group."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench: the {n_gpus} ranks did not finish within {timeout_s} s; ending them\n")
+        try:
+            os.killpg(child.pid, 15)
+            child.wait(timeout=20)
+        except (subprocess.TimeoutExpired, ProcessLookupError):
+            try:
+                os.killpg(child.pid, 9)
+            except ProcessLookupError:
+                pass
+        return 3
+    except KeyboardInterrupt:
+        os.killpg(child.pid, 15)
+        raise
+
+
 class Watchdog:
     """Multi-rank runs only: a collective that never completes (a rank missing, a link down) would otherwise hold
     every rank and the launcher until somebody kills them.  Each phase gets a deadline; when one passes, the rank
@@ -190,9 +223,11 @@ def main():
                          "code path of this script, the figure it prints is not a multi-GPU measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], 900 + 2 * (args.warmup + args.steps)))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: the launcher started another rank count")
 
     from sopht_mpi_amd import _lib
     from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
@@ -250,6 +285,7 @@ def main():
         "partition": "1 GPU" if args.gpus == 1 else f"{args.gpus} z-slabs",
         "transport": sim.ctx.transport,
         "rccl_ranks": args.gpus if sim.ctx.transport == "rccl" else 0,
+        "transpose_chunks": int(os.environ.get("SMI_FFT_TRANSPOSE_CHUNKS", "1")) if args.gpus > 1 else None,
         "poisson_backend": sim.unbounded_poisson_solver.backend,
         # fraction of the HBM peak the step reaches, on the bytes this implementation moves by design
         # (f32: advect + diffuse 9 S + 3 x Poisson 27 S + curl 6 S, S = 4 B per grid point)

@@ -216,6 +216,38 @@ int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per
   return 0;
 }
 
+// The same exchange for one slice of every block: block r starts at r * peer_stride and only its `bytes` bytes at
+// `offset` travel (one z chunk of every rank block of the spectral exchange layout).  `stage_send` / `stage_recv`
+// (nranks * bytes each) are only used by the host-staged callback transport, which wants contiguous blocks.
+int smi_alltoall_slice_impl(smi_ctx* c, const void* send, void* recv, size_t peer_stride, size_t offset, size_t bytes,
+                            void* stage_send, void* stage_recv, hipStream_t stream) {
+  const char* s0 = (const char*)send + offset;
+  char* r0 = (char*)recv + offset;
+  if (c->nranks == 1) {
+    if (send != recv) SMI_CHECK_HIP(hipMemcpyAsync(r0, s0, bytes, hipMemcpyDeviceToDevice, stream));
+    return 0;
+  }
+  if (c->alltoall_cb) {
+    SMI_REQUIRE(stage_send && stage_recv, "sliced all-to-all over a callback transport needs staging buffers");
+    SMI_CHECK_HIP(hipMemcpy2DAsync(stage_send, bytes, s0, peer_stride, bytes, c->nranks, hipMemcpyDeviceToDevice, stream));
+    int rc = c->alltoall_cb(c->exchange_user, stage_send, stage_recv, bytes);
+    SMI_REQUIRE(rc == 0, "all-to-all callback failed (%d)", rc);
+    SMI_CHECK_HIP(hipMemcpy2DAsync(r0, peer_stride, stage_recv, bytes, bytes, c->nranks, hipMemcpyDeviceToDevice, stream));
+    return 0;
+  }
+  SMI_REQUIRE(c->comm_ready, "all-to-all across ranks needs smi_comm_init or a transport callback");
+  SMI_CHECK_HIP(hipMemcpyAsync(r0 + (size_t)c->rank * peer_stride, s0 + (size_t)c->rank * peer_stride, bytes,
+                               hipMemcpyDeviceToDevice, stream));
+  SMI_CHECK_NCCL(ncclGroupStart());
+  for (int r = 0; r < c->nranks; ++r) {
+    if (r == c->rank) continue;
+    SMI_CHECK_NCCL(ncclSend(s0 + (size_t)r * peer_stride, bytes, ncclChar, r, c->comm, stream));
+    SMI_CHECK_NCCL(ncclRecv(r0 + (size_t)r * peer_stride, bytes, ncclChar, r, c->comm, stream));
+  }
+  SMI_CHECK_NCCL(ncclGroupEnd());
+  return 0;
+}
+
 extern "C" int smi_set_alltoall_callback(smi_ctx* c, smi_alltoall_cb cb) {
   SMI_REQUIRE(c, "smi_set_alltoall_callback: null context");
   c->alltoall_cb = cb;

@@ -572,6 +572,7 @@ struct PGeo {
   int colbase;  // column kernels: first spectral column of this launch (its tiles start there)
   int nct, n2, n3;  // column kernels: tiles per row, second and third extent of the launch
   int zg;           // y kernels: consecutive planes one workgroup walks over
+  int zl0;          // x kernels: first local plane of this launch (grid y counts planes from there)
 };
 
 // The column kernels run on a one-dimensional grid whose blocks are dealt to the eight XCDs
@@ -919,7 +920,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_fwd(const T* __restrict__ field, Cx<T>* __restrict__ out, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
+  const int c = G.c0 + blockIdx.z, zl = G.zl0 + blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
   const Cx<T> wh = tw4[item ? u : 0];  // exp(-i pi u / 2L)
   Cx<T> pre[8];
@@ -953,7 +954,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, true>::NT))
     k_fft_x_inv(const Cx<T>* __restrict__ in, T* __restrict__ field, PGeo G, FieldGeo F,
                 const Cx<T>* __restrict__ tw4) {
   FFT_KERNEL_PROLOGUE(true)
-  const int c = G.c0 + blockIdx.z, zl = blockIdx.y;
+  const int c = G.c0 + blockIdx.z, zl = G.zl0 + blockIdx.y;
   const size_t rank_stride = (size_t)G.nzl * G.ny * G.KXA;
   const Cx<T> wh = tw4[item ? u : 0];
   Cx<T> pre[8];
@@ -1011,6 +1012,8 @@ int ilog2(int n) {
 int smi_greens_spectrum_shifted(smi_ctx* c, int gnz, int gny, int gnx, double dx, double x_range, void** ghat_out);
 typedef int (*alltoall_fn)(smi_ctx*, const void*, void*, size_t);
 int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream);
+int smi_alltoall_slice_impl(smi_ctx* c, const void* send, void* recv, size_t peer_stride, size_t offset, size_t bytes,
+                            void* stage_send, void* stage_recv, hipStream_t stream);
 
 struct PrunedState {
   PGeo G;
@@ -1024,7 +1027,11 @@ struct PrunedState {
   // multi-rank: the transposes run on their own stream, one component at a time, so that they
   // overlap the transforms of the other components
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev[4][3] = {};
+  // per component: [0..3] forward chunk ready, [4] forward transpose done, [5] backward input ready,
+  // [6..9] backward chunk done
+  hipEvent_t ev[3][10] = {};
+  // host-staged test transport only: contiguous copies of one z chunk of every rank block
+  void* stage[2] = {nullptr, nullptr};
 };
 
 template <typename T>
@@ -1048,6 +1055,7 @@ int smi_pruned_destroy(smi_poisson* p) {
     for (auto& e : row)
       if (e) hipEventDestroy(e);
   if (s->comm_stream) hipStreamDestroy(s->comm_stream);
+  for (void* b : s->stage) hipFree(b);
   if (s->bufT && s->bufT != s->bufA) hipFree(s->bufT);
   hipFree(s->bufA);
   hipFree(s->bufB);
@@ -1102,6 +1110,7 @@ int smi_pruned_create(smi_poisson* p) {
   G.nc = 3;
   G.c0 = 0;
   G.colbase = 0;
+  G.zl0 = 0;
   G.KXL = (G.nx + G.P - 1) / G.P;
   G.KXP = (G.KXL + 15) / 16 * 16;
   // nx columns of a power-of-two grid make rows of a power-of-two pitch, and the column kernels walk down hundreds of
@@ -1219,25 +1228,29 @@ static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
   return launch_cols_tiles<T, LG, 0>(c, s, which, G, 0, G.KXL);
 }
 
+// planes [zl0, zl0 + nzc) of the local slab (nzc = 0: all of them)
 template <typename T, int LG>
-static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, void* field) {
+static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, void* field, int zl0 = 0, int nzc = 0) {
   PGeo G = s->G;
   G.nc = nc;
   G.c0 = c0;
+  G.zl0 = zl0;
+  if (nzc == 0) nzc = G.nzl - zl0;
+  const double share = (double)nzc / (double)G.nzl;
   using Cfg = TileCfg<T, LG, true>;
   constexpr int TS = Cfg::TS, NT = Cfg::NT;
   const size_t lds_bytes = Cfg::BYTES;
   FieldGeo F{c->g, c->px, (long long)c->plane, (long long)c->vol};
   const int xt = x_tiles<LG>(fwd);
-  dim3 grid((G.ny + TS * xt - 1) / (TS * xt), G.nzl, nc);
+  dim3 grid((G.ny + TS * xt - 1) / (TS * xt), nzc, nc);
   const Cx<T>* tw = (const Cx<T>*)s->tw[0];
   if (fwd) {
     SMI_CHECK(set_lds((const void*)k_fft_x_fwd<T, LG>, lds_bytes));
-    SmiProfScope prof(c, PROF_FFT_X_FWD, 3.0 * nc * smi_S(c));
+    SmiProfScope prof(c, PROF_FFT_X_FWD, 3.0 * nc * smi_S(c) * share);
     k_fft_x_fwd<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const T*)field, (Cx<T>*)s->bufA, G, F, tw);
   } else {
     SMI_CHECK(set_lds((const void*)k_fft_x_inv<T, LG>, lds_bytes));
-    SmiProfScope prof(c, PROF_FFT_X_INV, 3.0 * nc * smi_S(c));
+    SmiProfScope prof(c, PROF_FFT_X_INV, 3.0 * nc * smi_S(c) * share);
     k_fft_x_inv<T, LG><<<grid, NT, lds_bytes, c->stream>>>((const Cx<T>*)s->bufA, (T*)field, G, F, tw);
   }
   SMI_LAUNCH_CHECK();
@@ -1274,46 +1287,72 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
   // -> x_inv(k).  With RCCL the transposes go to the communication stream and events carry the
   // dependencies, so that a transpose overlaps the transforms of the neighbouring components;
   // a host-staged transport (callback) is synchronous and everything stays on one stream.
+  //
+  // Each transpose may be cut into C = 1, 2 or 4 chunks of local planes (context option transpose_chunks): a plane
+  // range is a contiguous slice of every rank block of the exchange layout, on the sending and on the receiving side.
+  // The x kernels then run chunk by chunk: x_fwd of chunk j + 1 runs under the transfer of chunk j, and x_inv of
+  // chunk j under the transfer of chunk j + 1, which shortens what is exposed at the two ends of the pipeline (the
+  // first forward and the last backward transpose) to one chunk.
   const size_t peer_bytes = (size_t)G.nzl * G.ny * G.KXA * cs;   // one component, one peer
   const size_t comp_bytes = peer_bytes * G.P;
   const bool overlap = !c->alltoall_cb;
   hipStream_t cstream = overlap ? s->comm_stream : c->stream;
-  // Invariant of the split: work on the communication stream is bracketed by events on BOTH sides.  A transpose
+  int C = c->opt_transpose_chunks;
+  while (C > 1 && G.nzl < C) C /= 2;
+  if (C > 1 && c->alltoall_cb && !s->stage[0]) {
+    const size_t stage_bytes = (size_t)((G.nzl + C - 1) / C) * G.ny * G.KXA * cs * G.P;
+    for (void*& b : s->stage) SMI_CHECK_HIP(hipMalloc(&b, stage_bytes));
+  }
+  auto chunk_lo = [&](int j) { return (int)((long long)G.nzl * j / C); };
+  // Invariant of the split: work on the communication stream is bracketed by events on BOTH sides.  A transfer
   // starts only after `ready` (recorded on the compute stream behind the kernel that produced its input), and the
   // compute stream waits for `done` before the kernel that consumes its output.  The last thing this function
   // queues on the compute stream waits for the last `done`, so when it returns the communication stream holds
   // nothing that the compute stream has not been ordered after: the caller may treat the solve as ordinary work on
   // c->stream, and the next solve may reuse bufA / bufT / the events without further synchronisation.
-  auto transpose = [&](int k, bool back, hipEvent_t ready, hipEvent_t done) -> int {
+  auto transfer = [&](int k, int j, bool back, hipEvent_t ready, hipEvent_t done) -> int {
     char* a = (char*)s->bufA + (size_t)k * comp_bytes;
     char* t = (char*)s->bufT + (size_t)k * comp_bytes;
+    const int z0 = chunk_lo(j), z1 = chunk_lo(j + 1);
+    const size_t off = (size_t)z0 * G.ny * G.KXA * cs, bytes = (size_t)(z1 - z0) * G.ny * G.KXA * cs;
+    auto run = [&]() -> int {
+      if (C == 1) return smi_alltoall_impl(c, back ? t : a, back ? a : t, peer_bytes, cstream);
+      return smi_alltoall_slice_impl(c, back ? t : a, back ? a : t, peer_bytes, off, bytes, s->stage[0], s->stage[1],
+                                     cstream);
+    };
     if (overlap) {
-      SMI_CHECK_HIP(hipEventRecord(ready, c->stream));
-      SMI_CHECK_HIP(hipStreamWaitEvent(cstream, ready, 0));
-      SMI_CHECK(smi_alltoall_impl(c, back ? t : a, back ? a : t, peer_bytes, cstream));
-      SMI_CHECK_HIP(hipEventRecord(done, cstream));
+      if (ready) {
+        SMI_CHECK_HIP(hipEventRecord(ready, c->stream));
+        SMI_CHECK_HIP(hipStreamWaitEvent(cstream, ready, 0));
+      }
+      SMI_CHECK(run());
+      if (done) SMI_CHECK_HIP(hipEventRecord(done, cstream));
     } else {
-      SmiProfScope prof(c, PROF_TRANSPOSE, (double)comp_bytes);
-      SMI_CHECK(smi_alltoall_impl(c, back ? t : a, back ? a : t, peer_bytes, cstream));
+      SmiProfScope prof(c, PROF_TRANSPOSE, (double)bytes * G.P);
+      SMI_CHECK(run());
     }
     return 0;
   };
   SMI_DISPATCH(c, {
+    for (int k = 0; k < ncomp; ++k)
+      for (int j = 0; j < C; ++j) {
+        const int z0 = chunk_lo(j), nzc = chunk_lo(j + 1) - z0;
+        LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, true, k, 1, (void*)rhs, z0, nzc)));)
+        SMI_CHECK(transfer(k, j, false, s->ev[k][j], j == C - 1 ? s->ev[k][4] : nullptr));
+      }
     for (int k = 0; k < ncomp; ++k) {
-      LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, true, k, 1, (void*)rhs)));)
-      SMI_CHECK(transpose(k, false, s->ev[0][k], s->ev[1][k]));
-    }
-    for (int k = 0; k < ncomp; ++k) {
-      if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[1][k], 0));
+      if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[k][4], 0));
       LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 0, k, 1)));)
       LG_SWITCH(s->lgz, SMI_CHECK((launch_cols<T, LG>(c, s, 1, k, 1)));)
       LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 2, k, 1)));)
-      SMI_CHECK(transpose(k, true, s->ev[2][k], s->ev[3][k]));
+      for (int j = 0; j < C; ++j) SMI_CHECK(transfer(k, j, true, j == 0 ? s->ev[k][5] : nullptr, s->ev[k][6 + j]));
     }
-    for (int k = 0; k < ncomp; ++k) {
-      if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[3][k], 0));
-      LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, false, k, 1, solution)));)
-    }
+    for (int k = 0; k < ncomp; ++k)
+      for (int j = 0; j < C; ++j) {
+        const int z0 = chunk_lo(j), nzc = chunk_lo(j + 1) - z0;
+        if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[k][6 + j], 0));
+        LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, false, k, 1, solution, z0, nzc)));)
+      }
   });
   return 0;
 }

@@ -945,7 +945,7 @@ __device__ __forceinline__ void atomic_max_nonneg(void* slot, double v) {
 template <typename T>
 __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out, const T* __restrict__ f, T pref,
                                                             Geo G, int zchunk, TileShape S, Const3<T> add,
-                                                            T* __restrict__ umax) {
+                                                            T* __restrict__ umax, int chunk0, int chunk_step) {
   extern __shared__ char smi_tile_smem[];
   T* lds = reinterpret_cast<T*>(smi_tile_smem);
   const Blk B = xcd_block<true>();
@@ -957,7 +957,8 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
 #pragma unroll
     for (int e = 0; e < 4; ++e) core[e] = yc && in_core(L.x0 + e, G.px, G.g);
   }
-  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  // chunk of this workgroup: chunk0 + chunk_step * (position along grid y), as in k_advect_diffuse
+  const int z0 = (chunk0 + chunk_step * B.y) * zchunk, z1 = min(z0 + zchunk, G.pz);
   const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
   const bool run = zs <= ze;  // uniform over the workgroup
   Pack<T, 4> band[3];  // value of a cell outside the compute set
@@ -1406,8 +1407,35 @@ template <int MODE>
 static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const double* add = nullptr,
                     bool track_max = false) {
   SMI_REQUIRE(out != f, "curl operators: output and input must not alias");
-  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
   Geo G = make_geo(c);
+  bool tiled = false;
+  SMI_DISPATCH(c, { tiled = MODE == 0 && vec_ok<T>(c, out, f); });
+  // Across z-slabs over RCCL the tiled curl runs the way the one-pass advection + diffusion kernel does: the ghost
+  // planes of `f` travel on the communication stream while the z chunks that cannot reach them are computed, and
+  // the chunks at the two ends of the slab follow behind the exchange (curl_mpi_3d.py:47-60: interior before halo).
+  // A chunk reads planes z0 - 1 .. z1, so the chunks out of reach are those with z0 >= g + 1 and z1 <= pz - g - 1.
+  TiledLaunch tl{};
+  int n_lo = 0, n_hi = 0, nchunks = 0;
+  bool overlap = false;
+  if (tiled) {
+    SMI_DISPATCH(c, { tl = tiled_launch<T>(c, 3, 1); });
+    nchunks = (int)tl.grid.y;
+    while (n_lo < nchunks && n_lo * tl.zchunk < c->g + 1) ++n_lo;
+    while (n_hi < nchunks - n_lo && (nchunks - n_hi) * tl.zchunk > c->pz - c->g - 1) ++n_hi;
+    overlap = smi_multi_rank(c) && !c->exchange_cb && c->nranks_y == 1 && nchunks - n_lo - n_hi >= 1;
+  }
+  if (smi_multi_rank(c)) {
+    if (overlap) {
+      // no RCCL call may be issued on c->stream while this exchange is pending on the communication stream: the
+      // launches below are plain kernels, and the stream waits for ev_b before anything else follows
+      SMI_CHECK_HIP(hipEventRecord(c->ev_a, c->stream));
+      SMI_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_a, 0));
+      SMI_CHECK(smi_halo_exchange2_on(c, f, 3, nullptr, 0, c->comm_stream));
+      SMI_CHECK_HIP(hipEventRecord(c->ev_b, c->comm_stream));
+    } else {
+      SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
+    }
+  }
   bool added = add == nullptr;
   c->umax_valid = 0;
   if (track_max)  // a fill kernel, not hipMemsetAsync: the step may be captured into a graph by a caller
@@ -1415,12 +1443,23 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
   {
     SmiProfScope prof(c, MODE == 0 ? PROF_CURL : PROF_CURL_UPDATE, (MODE == 0 ? 6.0 : 9.0) * smi_S(c));
     SMI_DISPATCH(c, {
-    if (MODE == 0 && vec_ok<T>(c, out, f)) {
-      const TiledLaunch t = tiled_launch<T>(c, 3, 1);
+    if (tiled) {
+      const TiledLaunch& t = tl;
       SMI_CHECK(allow_lds(k_curl_tiled<T>));
       const Const3<T> a = add ? Const3<T>{(T)add[0], (T)add[1], (T)add[2]} : Const3<T>{T(0), T(0), T(0)};
-      k_curl_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S, a,
-                                                                     track_max ? (T*)c->umax_slots : nullptr);
+      auto launch = [&](int chunk0, int count) {
+        if (count <= 0) return;
+        k_curl_tiled<T><<<dim3(t.grid.x, count, 1), t.threads, t.lds_bytes, c->stream>>>(
+            (T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S, a, track_max ? (T*)c->umax_slots : nullptr, chunk0, 1);
+      };
+      if (overlap) {
+        launch(n_lo, nchunks - n_lo - n_hi);
+        SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_b, 0));
+        launch(0, n_lo);
+        launch(nchunks - n_hi, n_hi);
+      } else {
+        launch(0, nchunks);
+      }
       added = true;
       if (track_max) {
         // cells outside the compute set (the zeroed bands) hold the constant alone

@@ -1,6 +1,7 @@
 """Worker of the full-size multi-rank test: the benchmark's own workload (seeded Gaussian blobs, navier_stokes,
-ghost 2) on the ranks it is launched on, a few steps, then diagnostics and per-plane sums of the interior written to
-files that the test compares between a single-rank run and a run over slabs."""
+ghost 2) on the ranks it is launched on, a few steps, then diagnostics, per-plane sums of the interior and - for the
+global planes named in the fourth argument (comma separated) - the whole interior planes of vorticity and velocity,
+written to files that the test compares between a single-rank run and a run over slabs."""
 import json
 import os
 import sys
@@ -17,6 +18,7 @@ from sopht_mpi_amd.world import get_world  # noqa: E402
 world = get_world()
 rank, size = world.rank, world.size
 n, steps, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+dump_planes = [int(z) for z in sys.argv[4].split(",")] if len(sys.argv) > 4 and sys.argv[4] else []
 real_t = np.float32
 sim = UnboundedFlowSimulator3D(grid_size=(n, n, n), x_range=1.0, kinematic_viscosity=1e-3, flow_type="navier_stokes",
                                real_t=real_t, ghost_size=2, penalty_zone_width=2)
@@ -34,6 +36,12 @@ w, u = sim.vorticity_field.get(), sim.velocity_field.get()
 planes = np.stack([w[k][inner].astype(np.float64).sum(axis=(1, 2)) for k in range(3)]
                   + [np.abs(u[k][inner]).astype(np.float64).sum(axis=(1, 2)) for k in range(3)])
 np.save(os.path.join(out_dir, f"planes_{size}_{rank}.npy"), planes)
+nzl = n // size
+for z in dump_planes:
+    if rank * nzl <= z < (rank + 1) * nzl:
+        zl = g + z - rank * nzl
+        np.save(os.path.join(out_dir, f"plane_{size}_{z}.npy"),
+                np.stack([w[k][zl, g:-g, g:-g] for k in range(3)] + [u[k][zl, g:-g, g:-g] for k in range(3)]))
 if rank == 0:
     with open(os.path.join(out_dir, f"diag_{size}.json"), "w") as f:
         json.dump(diag, f)

@@ -195,10 +195,10 @@ def test_nodes_formed_on_the_device_match_the_host_grid(smi, body, monkeypatch):
             it()
         # the reference-style host transfer of the device interactor's node forces uses the arms of the CURRENT pose
         dev.compute_flow_forces_and_torques()
-        f_host, t_host = np.zeros_like(dev.body_flow_forces), np.zeros_like(dev.body_flow_torques)
-        dev.forcing_grid.transfer_forcing_from_grid_to_body(f_host, t_host, dev.global_lag_grid_forcing_field)
-        assert_close(f_host, dev.body_flow_forces, np.float64, factor=1e3, what="host transfer of device forces")
-        assert_close(t_host, dev.body_flow_torques, np.float64, factor=1e3, what="host transfer of device torques")
+        body_f, body_t = np.zeros_like(dev.body_flow_forces), np.zeros_like(dev.body_flow_torques)
+        dev.forcing_grid.transfer_forcing_from_grid_to_body(body_f, body_t, dev.global_lag_grid_forcing_field)
+        assert_close(body_f, dev.body_flow_forces, np.float64, factor=1e3, what="host transfer of device forces")
+        assert_close(body_t, dev.body_flow_torques, np.float64, factor=1e3, what="host transfer of device torques")
         host.compute_flow_forces_and_torques()
         gd, gh = dev.forcing_grid, host.forcing_grid
         scale = np.abs(gh.position_field).max()

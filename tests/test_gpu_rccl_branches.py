@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STANDIN = os.path.join(ROOT, "tests", "rccl_standin", "libsophtmi_standin.so")
 
 
-def _run(worker, nranks, port, args, delay_ms=0):
+def _run(worker, nranks, port, args, delay_ms=0, chunks=1):
     if not os.path.exists(STANDIN):
         pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
     env = dict(os.environ)
@@ -32,6 +32,7 @@ def _run(worker, nranks, port, args, delay_ms=0):
     env["SOPHT_MI_TRANSPORT"] = "rccl"
     env["SOPHT_MPI_AMD_LIB"] = STANDIN
     env["SMI_STANDIN_DELAY_MS"] = str(delay_ms)
+    env["SMI_FFT_TRANSPOSE_CHUNKS"] = str(chunks)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", worker)] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -73,39 +74,67 @@ def test_transfers_held_back_by_milliseconds(worker, nranks, args):
     _run(worker, nranks, 29950 + nranks, args.split(), delay_ms=4)
 
 
-def _single_and_slabs(worker_name, n, steps, nranks, port, out_dir, extra_env=None):
+@pytest.mark.parametrize("delay_ms", [0, 4])
+@pytest.mark.parametrize("nranks,chunks,args", [
+    (2, 2, "navier_stokes fused 64x16x32 nofilter"),
+    (4, 4, "navier_stokes_with_forcing fused 64x32x64 nofilter"),
+    (4, 2, "navier_stokes fused 192x16x32"),
+    (8, 4, "navier_stokes_with_forcing fused 64x32x64"),     # slabs of 8 planes: chunks of 2
+    (8, 2, "navier_stokes_with_forcing fused 64x32x64"),
+])
+def test_transposes_in_z_chunks(nranks, chunks, args, delay_ms):
+    """Every spectral transpose cut into 2 or 4 chunks of planes (SMI_FFT_TRANSPOSE_CHUNKS): the x transforms of one
+    chunk run while another chunk travels on the communication stream.  With every transfer held back by 4 ms, an x
+    kernel that is not ordered behind the chunk it reads (or a transfer that starts before its chunk is written)
+    misses the oracle."""
+    _run("_slab_worker.py", nranks, 29960 + nranks + chunks, args.split(), delay_ms=delay_ms, chunks=chunks)
+
+
+def _single_and_slabs(worker_name, n, steps, nranks, port, out_dir, extra_env=None, extra_args=()):
     """Runs a worker on one rank (in-tree library) and on `nranks` ranks over the RCCL branches."""
     worker = os.path.join(ROOT, "tests", worker_name)
     env = dict(os.environ)
     for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SOPHT_MPI_AMD_LIB", "SOPHT_MI_TRANSPORT"):
         env.pop(key, None)
     env.update(extra_env or {})
-    single = subprocess.run([sys.executable, worker, str(n), str(steps), out_dir], env=env, capture_output=True,
-                            text=True, timeout=600)
+    single = subprocess.run([sys.executable, worker, str(n), str(steps), out_dir, *extra_args], env=env,
+                            capture_output=True, text=True, timeout=600)
     assert single.returncode == 0, _failure_digest(single)
     env["SOPHT_MI_TRANSPORT"] = "rccl"
     env["SOPHT_MPI_AMD_LIB"] = STANDIN
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), worker, str(n), str(steps), out_dir]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker, str(n), str(steps), out_dir, *extra_args]
     slabs = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert slabs.returncode == 0, _failure_digest(slabs)
     assert slabs.stdout.count("transport rccl") == nranks
 
 
-@pytest.mark.parametrize("n,nranks", [(512, 8), (512, 4), (512, 2)])
-def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, nranks):
+@pytest.mark.parametrize("n,nranks,chunks", [(512, 8, 4), (512, 8, 1), (512, 4, 2), (512, 2, 1)])
+def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, nranks, chunks):
     """The scaling configuration itself - the 512^3 benchmark workload cut into 8 z-slabs of 64 planes, 64 spectral
     columns per rank in rows of 512 bytes - run over the RCCL branches for two steps and compared with the single-rank run
-    of the same workload: time step, maximum vorticity, divergence norm, and the sum of every interior plane of the
-    vorticity and of |velocity| (a slab boundary that went wrong shows in the planes next to it)."""
+    of the same workload: time step, maximum vorticity, divergence norm, the sum of every interior plane of the
+    vorticity and of |velocity|, and - element by element - the two interior planes on either side of every slab
+    boundary plus one plane in the middle of a slab (a layout error that only shows at 64 columns per rank, a
+    swapped pair of rows inside a plane, would pass the sums)."""
     import json
 
     import numpy as np
 
+    from helpers import assert_close
+
     if not os.path.exists(STANDIN):
         pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
     out_dir = str(tmp_path)
-    _single_and_slabs("_full_size_ranks_worker.py", n, 2, nranks, 29990 + nranks, out_dir)
+    nzl = n // nranks
+    dump = sorted({b + d for b in range(nzl, n, nzl) for d in (-2, -1, 0, 1)} | {nzl // 2})
+    _single_and_slabs("_full_size_ranks_worker.py", n, 2, nranks, 29990 + nranks, out_dir,
+                      {"SMI_FFT_TRANSPOSE_CHUNKS": str(chunks)}, [",".join(map(str, dump))])
+    for z in dump:
+        one = np.load(os.path.join(out_dir, f"plane_1_{z}.npy"))
+        many = np.load(os.path.join(out_dir, f"plane_{nranks}_{z}.npy"))
+        for k, name in enumerate(("wx", "wy", "wz", "ux", "uy", "uz")):
+            assert_close(many[k], one[k], np.float32, factor=1.0, what=f"{name} of plane {z}, {nranks} slabs vs one")
     a = json.load(open(os.path.join(out_dir, "diag_1.json")))
     b = json.load(open(os.path.join(out_dir, f"diag_{nranks}.json")))
     assert abs(a["dt"] - b["dt"]) <= 1e-6 * a["dt"] and abs(a["dt_after"] - b["dt_after"]) <= 1e-5 * a["dt_after"]

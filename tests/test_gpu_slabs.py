@@ -40,9 +40,26 @@ def _failure_digest(out):
     (2, "navier_stokes_with_forcing", "unfused", "32x32x32 yslab"),
 ])
 def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
+    _slab_run(nranks, flow_type, mode, grid, chunks=1)
+
+
+@pytest.mark.parametrize("nranks,chunks,flow_type,mode,grid", [
+    (2, 2, "navier_stokes", "fused", "64x16x32 nofilter"),
+    (4, 4, "navier_stokes_with_forcing", "fused", "64x32x64 nofilter"),
+    (4, 2, "navier_stokes", "fused", "192x16x32"),
+    (8, 4, "navier_stokes_with_forcing", "fused", "64x32x64"),
+])
+def test_slab_flow_step_with_chunked_transposes(nranks, chunks, flow_type, mode, grid):
+    """The spectral transposes in 2 or 4 chunks of planes (SMI_FFT_TRANSPOSE_CHUNKS) over the host-staged transport:
+    the sliced exchange layout and the chunk-wise x transforms against the single-rank oracle."""
+    _slab_run(nranks, flow_type, mode, grid, chunks=chunks)
+
+
+def _slab_run(nranks, flow_type, mode, grid, chunks):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env["SOPHT_MI_TRANSPORT"] = "host"
+    env["SMI_FFT_TRANSPOSE_CHUNKS"] = str(chunks)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + nranks),
            os.path.join(ROOT, "tests", "_slab_worker.py"), flow_type, mode] + grid.split()
