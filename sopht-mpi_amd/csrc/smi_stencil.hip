@@ -649,10 +649,15 @@ struct FusedShape {
   int ntx, nty;    // tiles per plane
   int pitch;       // LDS row pitch in elements (the lane's vector starts at column 4 + 4 * its index)
 };
-constexpr int kFusedThreads = 1024;
+// Lanes per workgroup: 1024 in single precision (128 registers per lane); double precision holds twice the register
+// state per lane and runs 512 lanes (256 registers), with LDS tiles of the same byte size.
+template <typename T>
+constexpr int fused_threads() {
+  return sizeof(T) == 4 ? 1024 : 512;
+}
 
 template <typename T>
-__global__ void __launch_bounds__(kFusedThreads) k_advect_diffuse(T* __restrict__ out, const T* __restrict__ vel,
+__global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __restrict__ out, const T* __restrict__ vel,
                                                                  const T* __restrict__ vort, T pref, T cdiff, Geo G,
                                                                  int zchunk, FusedShape S, int chunk0,
                                                                  int chunk_step) {
@@ -779,7 +784,7 @@ __global__ void __launch_bounds__(kFusedThreads) k_advect_diffuse(T* __restrict_
   }
 }
 
-// Region shape for a padded plane of py rows x px / 4 vectors: the (rx, ry) with rx * ry <= kFusedThreads whose tiles
+// Region shape for a padded plane of py rows x px / 4 vectors: the (rx, ry) with rx * ry <= fused_threads<T>() whose tiles
 // (rx - 2 vectors x ry - 4 rows) cover the plane with the fewest lanes, the LDS budget permitting.
 template <typename T>
 static bool fused_shape(const smi_ctx* c, FusedShape& best) {
@@ -787,7 +792,7 @@ static bool fused_shape(const smi_ctx* c, FusedShape& best) {
   double best_cost = 1e300;
   bool found = false;
   for (int rx = 6; rx <= 128; ++rx) {
-    const int ry = kFusedThreads / rx;
+    const int ry = fused_threads<T>() / rx;
     if (ry < 6) break;
     const int ox = rx - 2, oy = ry - 4;
     const int ntx = (nl + ox - 1) / ox, nty = (c->py + oy - 1) / oy;
@@ -1609,9 +1614,9 @@ static int fused_zchunk(const smi_ctx* c, int tiles_per_plane) {
 }
 
 // out = advection update followed by the diffusion timestep of `vorticity`, in one pass (k_advect_diffuse).
-// *ran = 0 and nothing is launched when this context is not served by the fused kernel (double precision: the LDS
-// tiles do not fit; unaligned arrays; fewer than two ghost layers across ranks): the caller then runs the two
-// operators one after the other.
+// *ran = 0 and nothing is launched when this context is not served by the fused kernel (rows that are not whole
+// 4-element vectors; fewer than two ghost layers across ranks; pencils): the caller then runs the two operators one
+// after the other.
 // Across ranks the kernel needs u and w on BOTH ghost planes next to a neighbour (the advected vorticity of the
 // neighbour's edge plane is formed here from them, see Geo::za_lo), which one exchange of depth 2 delivers, in place
 // of the two exchanges of depth 1 of the two-pass path.  That exchange runs on the communication stream while the
@@ -1621,25 +1626,34 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
                             int* ran) {
   *ran = 0;
   SMI_REQUIRE(out != velocity && out != vorticity, "advection-diffusion: output and input must not alias");
-  if (c->dtype != SMI_F32 || c->opt_no_fused) return 0;
+  if (c->opt_no_fused) return 0;
   if (smi_multi_rank(c) && c->g < 2) return 0;
   // across an inner y face the advected vorticity of the neighbour's edge row would have to be formed here as it
   // is for z (Geo::za_lo); a pencil runs the two operators one after the other instead
   if (c->nranks_y > 1) return 0;
-  if (!(vec_ok<float>(c, out, velocity) && vec_ok<float>(c, out, vorticity))) return 0;
+  bool aligned = false;
   FusedShape S;
-  if (!fused_shape<float>(c, S)) return 0;
+  bool shaped = false;
+  SMI_DISPATCH(c, {
+    aligned = vec_ok<T>(c, out, velocity) && vec_ok<T>(c, out, vorticity);
+    shaped = fused_shape<T>(c, S);
+  });
+  if (!aligned || !shaped) return 0;
   Geo G = make_geo(c);
-  const size_t lds_bytes = (size_t)6 * (S.ry + 2) * S.pitch * sizeof(float);
-  SMI_CHECK_HIP(hipFuncSetAttribute((const void*)k_advect_diffuse<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
+  const size_t lds_bytes = (size_t)6 * (S.ry + 2) * S.pitch * smi_elem_size(c);
+  SMI_DISPATCH(c, {
+    SMI_CHECK_HIP(hipFuncSetAttribute((const void*)k_advect_diffuse<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_bytes));
+  });
   const int zchunk = fused_zchunk(c, S.ntx * S.nty);
   const int nchunks = (c->pz + zchunk - 1) / zchunk;
   auto launch = [&](int chunk0, int step, int count) {
     dim3 grid(S.ntx * S.nty, count, 1);
-    k_advect_diffuse<float><<<grid, kFusedThreads, lds_bytes, c->stream>>>((float*)out, (const float*)velocity,
-                                                                          (const float*)vorticity, (float)pref_curl,
-                                                                          (float)pref_diff, G, zchunk, S, chunk0, step);
+    SMI_DISPATCH(c, {
+      k_advect_diffuse<T><<<grid, fused_threads<T>(), lds_bytes, c->stream>>>((T*)out, (const T*)velocity,
+                                                                             (const T*)vorticity, (T)pref_curl,
+                                                                             (T)pref_diff, G, zchunk, S, chunk0, step);
+    });
   };
   if (!smi_multi_rank(c)) {
     SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));

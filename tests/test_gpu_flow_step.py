@@ -71,6 +71,8 @@ def test_navier_stokes_steps(smi, n, flow_type, free_stream, filt, real_t, fused
     gpu.compute_flow_velocity(free_stream_velocity=fs)
     cpu.compute_flow_velocity(free_stream_velocity=fs)
     assert_close(gpu.velocity_field.get(), cpu.velocity_field, real_t, factor=2.0, what="initial velocity")
+    smi._lib.call("smi_prof_enable", gpu.ctx.handle, 1)
+    smi._lib.call("smi_prof_reset", gpu.ctx.handle)
     for step in range(3):
         dt_gpu = gpu.compute_stable_timestep(dt_prefac=0.5)
         dt_cpu = cpu.compute_stable_timestep(dt_prefac=0.5)
@@ -92,6 +94,11 @@ def test_navier_stokes_steps(smi, n, flow_type, free_stream, filt, real_t, fused
         assert_close(gpu.vorticity_field.get(), cpu.vorticity_field, real_t, factor=1.0 + 0.5 * step,
                      what=f"vorticity incl. ghosts step {step}")
     assert gpu.time == cpu.time
+    slots = smi._lib.prof_collect(gpu.ctx)
+    smi._lib.call("smi_prof_enable", gpu.ctx.handle, 0)
+    if fused and gpu.ctx.padded_shape[2] % 4 == 0:
+        # both precisions take advection and diffusion through the one-pass kernel
+        assert slots.get("fused_advect_diffuse", {}).get("launches", 0) == 3, sorted(slots)
     if flow_type == "navier_stokes_with_forcing":
         assert not np.any(gpu.eul_grid_forcing_field.get())
     assert abs(float(gpu.get_max_vorticity()) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(

@@ -298,15 +298,15 @@ def test_tiled_kernels_on_random_shapes(smi, shape, g):
     assert np.array_equal(du.get(), u) and np.array_equal(df.get(), f), "inputs were modified"
 
 
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
 @pytest.mark.parametrize("zchunk", [None, "8", "13"])
 @pytest.mark.parametrize("shape,g", [((40, 70, 260), 2), ((24, 100, 60), 2), ((8, 8, 8), 2), ((33, 45, 124), 2),
                                      ((16, 16, 34), 3), ((50, 21, 512), 2)])
-def test_fused_advection_diffusion_shapes(smi, shape, g, zchunk, monkeypatch):
-    """The one-pass advection + diffusion kernel (single precision) on grids with one to several tiles per plane,
+def test_fused_advection_diffusion_shapes(smi, shape, g, zchunk, real_t):
+    """The one-pass advection + diffusion kernel (1024 lanes in single, 512 in double precision) on grids with one to several tiles per plane,
     partial tiles in both directions and, through the fused_zchunk option, one to several z chunks with partial last
     chunks: against the reference's operator sequence (cross product, vorticity update, diffusion timestep)
     on the whole array, ghost cells included, and against the two-pass path of the library bit for bit."""
-    real_t = np.float32
     rng = np.random.default_rng(sum(shape))
     ctx = make_ctx(smi, shape, g, real_t)
     if zchunk is not None:
@@ -318,7 +318,11 @@ def test_fused_advection_diffusion_shapes(smi, shape, g, zchunk, monkeypatch):
     du, dw = ctx.from_numpy(u), ctx.from_numpy(w)
     dscr = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
     dout = ctx.from_numpy(rand_field(rng, (3,) + ctx.padded_shape, real_t))
+    smi._lib.call("smi_prof_enable", ctx.handle, 1)
+    smi._lib.call("smi_prof_reset", ctx.handle)
     _call(smi, "smi_advection_diffusion_update", ctx.handle, dout.ptr, du.ptr, dw.ptr, dscr.ptr, float(p), float(c))
+    assert smi._lib.prof_collect(ctx).get("fused_advect_diffuse", {}).get("launches", 0) >= 1, "the one-pass kernel did not run"
+    smi._lib.call("smi_prof_enable", ctx.handle, 0)
     cross = np.zeros_like(w)
     st.elementwise_cross_product(cross, u, w)
     want = w.copy()
