@@ -323,6 +323,25 @@ class VirtualBoundaryForcingMPI:
         comm.gather_local_field(self.global_lag_grid_velocity_mismatch_field,
                                 self.local_lag_grid_velocity_mismatch_field.get())
 
+    def scatter_global_mismatch_fields(self, global_lag_grid_position_field=None):
+        """The converse, for a restart: the global mismatch arrays (just read from a file on the master rank) go to the
+        device arrays of the slabs that own the nodes at ``global_lag_grid_position_field`` - the re-map, buffer
+        re-initialisation and two scatters of flow_past_freely_rotating_rod_case.py:228-247 in one call."""
+        if self.assume_data_locality or self.mpi_construct.size == 1:
+            self.local_lag_grid_position_mismatch_field.set(self.global_lag_grid_position_mismatch_field)
+            self.local_lag_grid_velocity_mismatch_field.set(self.global_lag_grid_velocity_mismatch_field)
+            return
+        comm = self.mpi_lagrangian_field_communicator
+        comm.map_lagrangian_nodes_based_on_position(global_lag_grid_position_field)
+        self.local_num_lag_nodes = comm.local_num_lag_nodes
+        self._init_local_buffers(self.local_num_lag_nodes)
+        pm = np.zeros((self.grid_dim, self.local_num_lag_nodes))
+        vm = np.zeros_like(pm)
+        comm.scatter_global_field(pm, self.global_lag_grid_position_mismatch_field)
+        comm.scatter_global_field(vm, self.global_lag_grid_velocity_mismatch_field)
+        self.local_lag_grid_position_mismatch_field.set(pm)
+        self.local_lag_grid_velocity_mismatch_field.set(vm)
+
     # ---------------------------------------------------------------- the pointwise kernels, one at a time
     @staticmethod
     def _axpby(out, a, x, b, y):

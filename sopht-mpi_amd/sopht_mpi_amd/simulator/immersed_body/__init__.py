@@ -11,3 +11,4 @@ from .forcing_grids import (  # noqa: F401,E402
     SphereForcingGrid,
     StraightRodBody,
 )
+from .rigid_body_dynamics import RigidBodyIntegrator, rod_mass_and_inertia, sphere_mass_and_inertia  # noqa: F401,E402
