@@ -127,14 +127,15 @@ __device__ __forceinline__ void dft8(Cx<T> (&v)[8]) {
 
 // Compile-time plan of an L point transform.  The template key LG is log2(L) for powers of
 // two (radix-8 stages, then one radix-4 or radix-2 stage for the remainder) and L itself for
-// L = 64 R with R = 3, 6, 12 (192, 384, 768): three stages of radix 8, R, 8.  Every index
+// L = 64 R with R = 3, 5, 6, 10, 12 (192, 320, 384, 640, 768): three stages of radix 8, R, 8.  Every index
 // below folds to constants.
 template <int LG>
 struct Plan {
   static constexpr bool POW2 = LG < 32;
   static constexpr int L = POW2 ? (1 << (POW2 ? LG : 0)) : LG, L8 = L / 8;
   static constexpr int RM = POW2 ? 0 : L / 64;  // middle radix of the 8 x R x 8 plans
-  static_assert(POW2 || (L % 64 == 0 && (RM == 3 || RM == 6 || RM == 12)), "unsupported transform length");
+  static_assert(POW2 || (L % 64 == 0 && (RM == 3 || RM == 5 || RM == 6 || RM == 10 || RM == 12)),
+                "unsupported transform length");
   static constexpr int N8 = POW2 ? LG / 3 : 0, REM = POW2 ? LG % 3 : 0, NST = POW2 ? N8 + (REM ? 1 : 0) : 3;
   // threads per sequence: one per work item of 8 points; the 64 items of the middle stage of a
   // mixed plan need 64 lanes, or 32 that take MI = 2 items each when those are three points wide
@@ -413,11 +414,44 @@ __device__ __forceinline__ void dft3(Cx<T>& a, Cx<T>& b, Cx<T>& c) {
   c = m - id;
 }
 
-// x[0..R-1] -> DFT_R in place (natural order in, natural order out), R = 3, 6, 12
+template <int SIGN, typename T>
+__device__ __forceinline__ void dft5(Cx<T>& x0, Cx<T>& x1, Cx<T>& x2, Cx<T>& x3, Cx<T>& x4) {
+  const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;              // cos(2 pi / 5), cos(4 pi / 5)
+  const T s1 = (T)(SIGN * 0.95105651629515357212), s2 = (T)(SIGN * 0.58778525229247312917);  // SIGN sin(...)
+  const Cx<T> t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+  const Cx<T> a1{x0.x + c1 * t1.x + c2 * t2.x, x0.y + c1 * t1.y + c2 * t2.y};
+  const Cx<T> a2{x0.x + c2 * t1.x + c1 * t2.x, x0.y + c2 * t1.y + c1 * t2.y};
+  const Cx<T> b1{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y}, b2{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y};
+  const Cx<T> ib1{-b1.y, b1.x}, ib2{-b2.y, b2.x};  // i b
+  x0 = x0 + t1 + t2;
+  x1 = a1 + ib1;
+  x4 = a1 - ib1;
+  x2 = a2 + ib2;
+  x3 = a2 - ib2;
+}
+
+// x[0..R-1] -> DFT_R in place (natural order in, natural order out), R = 3, 5, 6, 10, 12
 template <int SIGN, int R, typename T>
 __device__ __forceinline__ void dft_mid(Cx<T> (&x)[12]) {
   if constexpr (R == 3) {
     dft3<SIGN>(x[0], x[1], x[2]);
+  } else if constexpr (R == 5) {
+    dft5<SIGN>(x[0], x[1], x[2], x[3], x[4]);
+  } else if constexpr (R == 10) {
+    // n = 2 n1 + n2, k = k1 + 5 k2
+    Cx<T> e[5] = {x[0], x[2], x[4], x[6], x[8]}, o[5] = {x[1], x[3], x[5], x[7], x[9]};
+    dft5<SIGN>(e[0], e[1], e[2], e[3], e[4]);
+    dft5<SIGN>(o[0], o[1], o[2], o[3], o[4]);
+    const T s = (T)SIGN;
+    o[1] = o[1] * Cx<T>{(T)0.80901699437494742410, s * (T)0.58778525229247312917};    // w10
+    o[2] = o[2] * Cx<T>{(T)0.30901699437494742410, s * (T)0.95105651629515357212};    // w10^2
+    o[3] = o[3] * Cx<T>{(T)-0.30901699437494742410, s * (T)0.95105651629515357212};   // w10^3
+    o[4] = o[4] * Cx<T>{(T)-0.80901699437494742410, s * (T)0.58778525229247312917};   // w10^4
+#pragma unroll
+    for (int k1 = 0; k1 < 5; ++k1) {
+      x[k1] = e[k1] + o[k1];
+      x[k1 + 5] = e[k1] - o[k1];
+    }
   } else if constexpr (R == 6) {
     // n = 2 n1 + n2, k = k1 + 3 k2
     Cx<T> e0 = x[0], e1 = x[2], e2 = x[4], o0 = x[1], o1 = x[3], o2 = x[5];
@@ -995,10 +1029,11 @@ __global__ void __launch_bounds__(kThreads) k_fold_green(T* __restrict__ green, 
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 int ilog2(int n);
-// template key of the plan for an n-point transform (see Plan): log2(n), n itself for 192 / 384 / 768, 0 if none
+// template key of the plan for an n-point transform (see Plan): log2(n), n itself for 192 / 320 / 384 / 640 / 768,
+// 0 if none
 int plan_key(int n) {
   if (is_pow2(n) && n >= 8 && n <= 2048) return ilog2(n);
-  return (n == 192 || n == 384 || n == 768) ? n : 0;
+  return (n == 192 || n == 320 || n == 384 || n == 640 || n == 768) ? n : 0;
 }
 
 int ilog2(int n) {
@@ -1095,7 +1130,8 @@ bool smi_pruned_supports(int gnz, int gny, int gnx) {
 int smi_pruned_create(smi_poisson* p) {
   smi_ctx* c = p->ctx;
   SMI_REQUIRE(plan_key(p->gnx) && plan_key(p->gny) && plan_key(p->gnz) && p->gnx >= 8 && p->gny >= 8 && p->gnz >= 8,
-              "SMI_POISSON_PRUNED needs transform lengths nx, ny, nz that are powers of two (8 .. 2048) or 192, 384, 768 "
+              "SMI_POISSON_PRUNED needs transform lengths nx, ny, nz that are powers of two (8 .. 2048) or 192, 320, 384, "
+              "640, 768 "
               "(got %d %d %d)",
               p->gnz, p->gny, p->gnx);
   SMI_REQUIRE(p->gnx <= 2048 && p->gny <= 2048 && p->gnz <= 2048, "SMI_POISSON_PRUNED: grid too large");
@@ -1263,6 +1299,7 @@ static int launch_rows(smi_ctx* c, PrunedState* s, bool fwd, int c0, int nc, voi
     LG_CASE(3, __VA_ARGS__) LG_CASE(4, __VA_ARGS__) LG_CASE(5, __VA_ARGS__) LG_CASE(6, __VA_ARGS__) \
     LG_CASE(7, __VA_ARGS__) LG_CASE(8, __VA_ARGS__) LG_CASE(9, __VA_ARGS__) LG_CASE(10, __VA_ARGS__) \
     LG_CASE(11, __VA_ARGS__) LG_CASE(192, __VA_ARGS__) LG_CASE(384, __VA_ARGS__) LG_CASE(768, __VA_ARGS__) \
+    LG_CASE(320, __VA_ARGS__) LG_CASE(640, __VA_ARGS__)                                          \
     default: smi_set_error("unsupported transform length 2^%d", lg); return 1;                  \
   }
 

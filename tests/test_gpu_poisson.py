@@ -18,6 +18,8 @@ SHAPES = [((8, 8, 8), 2), ((16, 16, 16), 2), ((8, 16, 32), 1), ((32, 32, 32), 2)
           # transform lengths 192, 384, 768 (radix 8 x R x 8 plans) on each axis
           ((8, 192, 384), 2), ((384, 8, 768), 2), ((8, 384, 16), 2), ((192, 8, 16), 2),
           ((768, 8, 16), 2), ((8, 768, 16), 2), ((8, 8, 768), 2),
+          # 320 and 640 (radix 8 x 5 x 8 and 8 x 10 x 8)
+          ((320, 8, 16), 2), ((8, 320, 640), 2), ((8, 8, 320), 2), ((640, 8, 16), 2), ((8, 640, 16), 2),
           # the longest power-of-two plans
           ((1024, 8, 16), 2), ((8, 2048, 16), 2), ((8, 8, 2048), 2),
           # the benchmark's length on the z axis
@@ -26,7 +28,7 @@ SHAPES = [((8, 8, 8), 2), ((16, 16, 16), 2), ((8, 16, 32), 1), ((32, 32, 32), 2)
 
 def _supported(shape, backend):
     """smi_poisson_supports, asked without a GPU (collection time): the pruned back end has no plan for x rows
-    shorter than 16 cells or for lengths that are neither powers of two nor 192 / 384 / 768."""
+    shorter than 16 cells or for lengths that are neither powers of two nor 192 / 320 / 384 / 640 / 768."""
     from sopht_mpi_amd._lib import lib
 
     return bool(lib.smi_poisson_supports(shape[0], shape[1], shape[2], 1, CODES[backend]))

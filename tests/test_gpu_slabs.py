@@ -30,6 +30,7 @@ def _failure_digest(out):
     (2, "navier_stokes_with_forcing", "fused", "32x16x32"),
     (4, "navier_stokes_with_forcing", "fused", "32x16x32"),
     (4, "navier_stokes", "fused", "192x16x32"),   # a 192-point (radix 8 x 3 x 8) transform across the slabs
+    (4, "navier_stokes", "fused", "320x16x32"),   # a 320-point (radix 8 x 5 x 8) transform across the slabs
     (8, "navier_stokes_with_forcing", "fused", "64x32x64"),  # the largest rank count of the scaling runs: 8 of 64 columns per rank
     # pencils over z and y (the reference's default decomposition): y faces, edges, the ghost sum's cascade, node
     # ownership by (z, y) block, the Poisson solve through the slab decomposition
