@@ -40,7 +40,7 @@ IMPL_BYTES_PER_POINT_STEP = {"f32": 96 * 4.0, "f64": 102 * 8.0}
 # rocprofv3 --pmc counters of every hot kernel (tools/pmc_bench.sh + tools/make_counters_json.py); they are not
 # measured inside this run: the file records the hash of the library sources it was collected on, and its figures
 # are withheld when that differs from the sources in this tree
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_counters_512cubed.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_counters_512cubed.json")
 
 
 def lib_source_hash():
