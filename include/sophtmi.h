@@ -103,6 +103,12 @@ int smi_set_sendrecv_callback(smi_ctx* ctx, smi_sendrecv_cb cb);
 typedef int (*smi_group_alltoall_cb)(void* user, const void* send, void* recv, size_t bytes_per_peer,
                                      int first_rank, int count);
 int smi_set_group_alltoall_callback(smi_ctx* ctx, smi_group_alltoall_cb cb);
+/* ... and a few point-to-point messages of `bytes` bytes each between device buffers (the Isend / Irecv pairs of
+ * MPIDomainDoublingCommunicator3D, UnboundedPoissonSolverMPI3D.py:314-382): sends[i] goes to rank send_peers[i],
+ * recvs[j] comes from rank recv_peers[j]. */
+typedef int (*smi_p2p_cb)(void* user, int nsend, const int* send_peers, const void* const* sends, int nrecv,
+                          const int* recv_peers, void* const* recvs, size_t bytes);
+int smi_set_p2p_callback(smi_ctx* ctx, smi_p2p_cb cb);
 /* MPIDomainDoublingCommunicator-style redistribution between the two decompositions of one grid:
  * `pencil_field` (ncomp components, ghosted, on `pencil`) <-> `slab_field` (ghosted, on `slab`, a context of
  * the same rank and rank count created with nz = global nz / nranks, ny = global ny).  Interiors only.
@@ -256,10 +262,12 @@ size_t smi_poisson_noalloc_capacity(void);
 size_t smi_poisson_greens_size(smi_poisson* p);
 int smi_poisson_greens_download(smi_poisson* p, void* host);
 
-/* ---- stand-alone FFT plans and doubled-domain copies (single rank) --------------------------
+/* ---- stand-alone FFT plans and doubled-domain copies ------------------------------------------
  * FFTMPI3D (poisson_solver_3d/fft_mpi_3d.py:5-48) / FFTMPI2D (poisson_solver_2d/fft_mpi_2d.py:5-45):
  * real (nz, ny, nx) <-> complex (nz, ny, nx/2 + 1), contiguous, no ghosts; nz = 1 makes a 2D plan.
- * forward is unnormalised, backward divides by nz*ny*nx and leaves its input intact. */
+ * forward is unnormalised, backward divides by nz*ny*nx and leaves its input intact.
+ * nz, ny, nx are the GLOBAL sizes.  On a context of P z-slabs (3D) the arrays are mpi4py-fft's for a slab
+ * decomposition: real (nz / P, ny, nx) per rank, spectrum (nz, ny / P, nx/2 + 1) per rank; P must divide nz and ny. */
 typedef struct smi_fft smi_fft;
 int smi_fft_create(smi_fft** out, smi_ctx* ctx, int nz, int ny, int nx);
 int smi_fft_destroy(smi_fft* f);
@@ -267,7 +275,9 @@ int smi_fft_forward(smi_fft* f, const void* field, void* fourier_field);
 int smi_fft_backward(smi_fft* f, const void* fourier_field, void* inv_fourier_field);
 /* MPIDomainDoublingCommunicator3D.copy_to_doubled_domain / copy_from_doubled_domain
  * (UnboundedPoissonSolverMPI3D.py:314-382; 2D: UnboundedPoissonSolverMPI2D.py:273-352): interior of
- * the ghosted local field <-> first octant (quadrant) of the contiguous doubled array. */
+ * the ghosted local field <-> first octant (quadrant) of the contiguous doubled array.  On P z-slabs (P even)
+ * local_doubled_field is this rank's (2 nz_local, 2 ny, 2 nx) slab of the doubled grid: the blocks of ranks 2r and
+ * 2r + 1 arrive on rank r < P / 2, the other ranks hold padding only. */
 int smi_copy_to_doubled_domain(smi_ctx* ctx, const void* local_field, void* local_doubled_field);
 int smi_copy_from_doubled_domain(smi_ctx* ctx, const void* local_doubled_field, void* local_field);
 

@@ -33,6 +33,9 @@ struct smi_ctx {
   size_t ybuf_cap;
   smi_sendrecv_cb sendrecv_cb;
   smi_group_alltoall_cb group_alltoall_cb;
+  smi_p2p_cb p2p_cb;
+  void* dbl_stage[3];    // staging blocks of the doubled-domain copies across ranks (smi_fftapi.hip)
+  size_t dbl_stage_cap;
   hipStream_t stream;
   hipStream_t comm_stream;
   hipEvent_t ev_a, ev_b;

@@ -159,6 +159,8 @@ extern "C" int smi_ctx_destroy(smi_ctx* c) {
   for (int i = 0; i < 4; ++i) {
     if (c->ybuf[i]) hipFree(c->ybuf[i]);
   }
+  for (void* b : c->dbl_stage)
+    if (b) hipFree(b);
   delete c->prof;
   if (c->red_partials) hipFree(c->red_partials);
   if (c->fac_dev) hipFree(c->fac_dev);

@@ -37,6 +37,8 @@ ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_
 SENDRECV_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_size_t)
 GROUP_ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+P2P_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int,
+                     C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_size_t)
 
 # name -> argtypes; every function returns int status unless listed in _SPECIAL
 SIGNATURES = {
@@ -51,6 +53,7 @@ SIGNATURES = {
     "smi_ctx_set_pencil": [_p, _i, _i, _i, _i],
     "smi_set_sendrecv_callback": [_p, SENDRECV_CB],
     "smi_set_group_alltoall_callback": [_p, GROUP_ALLTOALL_CB],
+    "smi_set_p2p_callback": [_p, P2P_CB],
     "smi_pencil_to_slab": [_p, _p, _p, _p, _i, _p, _p],
     "smi_slab_to_pencil": [_p, _p, _p, _p, _i, _p, _p],
     "smi_allreduce_f64": [_p, _dp, _i, _i],

@@ -178,6 +178,32 @@ class DeviceContext:
                 self._cb_error = exc
                 return 1
 
+        def p2p(_user, nsend, send_peers, sends, nrecv, recv_peers, recvs, nbytes):
+            """A few equal-sized messages between device buffers; one to this rank itself is a copy."""
+            try:
+                out, into, own = {}, {}, None
+                for i in range(nsend):
+                    host = np.empty(nbytes, dtype=np.uint8)
+                    call("smi_memcpy_d2h", self.handle, host.ctypes.data, sends[i], nbytes)
+                    if send_peers[i] == self.rank:
+                        own = host
+                    else:
+                        out[send_peers[i]] = host
+                for j in range(nrecv):
+                    if recv_peers[j] != self.rank:
+                        into[recv_peers[j]] = (np.empty(nbytes, dtype=np.uint8), recvs[j])
+                self.world.sendrecv(out, {peer: buf for peer, (buf, _) in into.items()})
+                for j in range(nrecv):
+                    host = own if recv_peers[j] == self.rank else into[recv_peers[j]][0]
+                    call("smi_memcpy_h2d", self.handle, recvs[j], host.ctypes.data, nbytes)
+                return 0
+            except Exception as exc:
+                import traceback
+
+                traceback.print_exc()
+                self._cb_error = exc
+                return 1
+
         self._cb = _lib.EXCHANGE_CB(exchange)
         self._cb2 = _lib.ALLTOALL_CB(alltoall)
         self._cb3 = _lib.SENDRECV_CB(sendrecv)
@@ -186,6 +212,8 @@ class DeviceContext:
         call("smi_set_alltoall_callback", self.handle, self._cb2)
         call("smi_set_sendrecv_callback", self.handle, self._cb3)
         call("smi_set_group_alltoall_callback", self.handle, self._cb4)
+        self._cb5 = _lib.P2P_CB(p2p)
+        call("smi_set_p2p_callback", self.handle, self._cb5)
         self.transport = "host"
 
     def allreduce(self, value, op):

@@ -327,23 +327,33 @@ class _DeviceFFT:
     the reference's buffers and normalisation (forward unnormalised, backward normalised)."""
 
     def _setup(self, shape, mpi_construct, real_t):
-        if mpi_construct.size > 1:
-            raise RuntimeError(
-                "the stand-alone FFT runs on one rank; across slabs the transform is part of "
-                "UnboundedPoissonSolverMPI3D (pruned back end)"
-            )
         self.real_dtype = np.dtype(real_t).type
         if self.real_dtype not in (np.float32, np.float64):
             raise ValueError(f"unsupported real type {real_t}")
         self.complex_dtype = np.complex64 if self.real_dtype == np.float32 else np.complex128
         if np.dtype(mpi_construct.real_t) != np.dtype(real_t):
             raise ValueError("real_t differs from the precision of mpi_construct")
-        self.ctx = mpi_construct.device_context(2)
-        self.shape = tuple(int(n) for n in shape)
-        self.fourier_shape = self.shape[:-1] + (self.shape[-1] // 2 + 1,)
+        self.global_shape = tuple(int(n) for n in shape)
+        nranks = mpi_construct.size
+        if nranks > 1:
+            # mpi4py-fft's layouts for a slab decomposition (fft_mpi_3d.py:19-33): the real array divided along z,
+            # its spectrum along y
+            topo = tuple(int(t) for t in mpi_construct.grid_topology)
+            if len(self.global_shape) != 3 or topo[1:] != (1, 1):
+                raise RuntimeError("across ranks the stand-alone FFT serves z-slabs of a 3D grid")
+            nz, ny, nx = self.global_shape
+            if nz % nranks or ny % nranks:
+                raise RuntimeError(f"{nranks} ranks must divide the z and y extents of the grid {self.global_shape}")
+            self.ctx = mpi_construct.device_context(2)   # rank, stream and transport; the plan takes global sizes
+            self.shape = (nz // nranks, ny, nx)
+            self.fourier_shape = (nz, ny // nranks, nx // 2 + 1)
+        else:
+            self.ctx = mpi_construct.device_context(2)
+            self.shape = self.global_shape
+            self.fourier_shape = self.shape[:-1] + (self.shape[-1] // 2 + 1,)
         self.field_buffer = self.ctx.zeros(self.shape, self.real_dtype)
         self.fourier_field_buffer = self.ctx.zeros(self.fourier_shape, self.complex_dtype)
-        nz, ny, nx = ((1,) + self.shape)[-3:]
+        nz, ny, nx = ((1,) + self.global_shape)[-3:]
         h = C.c_void_p()
         call("smi_fft_create", C.byref(h), self.ctx.handle, nz, ny, nx)
         self.handle = h
@@ -374,7 +384,8 @@ class _DeviceFFT:
 
 
 class FFTMPI3D(_DeviceFFT):
-    """poisson_solver_3d/fft_mpi_3d.py:5-48: real (z, y, x) <-> complex (z, y, x/2 + 1) DeviceFields."""
+    """poisson_solver_3d/fft_mpi_3d.py:5-48: real (z, y, x) <-> complex (z, y, x/2 + 1) DeviceFields; across P z-slabs
+    real (z / P, y, x) <-> complex (z, y / P, x/2 + 1) per rank, the layouts of mpi4py-fft's slab transform."""
 
     def __init__(self, grid_size_z, grid_size_y, grid_size_x, mpi_construct, real_t=np.float64):
         self.grid_size_z, self.grid_size_y, self.grid_size_x = grid_size_z, grid_size_y, grid_size_x
@@ -386,10 +397,9 @@ class _DomainDoubling:
         if ghost_size < 0 or not isinstance(ghost_size, (int, np.integer)):
             raise ValueError(f"Ghost size {ghost_size} needs to be an integer >= 0 for field communication.")
         if mpi_construct.size > 1:
-            raise RuntimeError(
-                "the doubled-domain copies run on one rank; across slabs the Poisson solver never builds "
-                "the doubled arrays"
-            )
+            topo = tuple(int(t) for t in mpi_construct.grid_topology)
+            if len(topo) != 3 or topo[1:] != (1, 1) or topo[0] % 2:
+                raise RuntimeError("across ranks the doubled-domain copies serve an even number of z-slabs of a 3D grid")
         if ghost_size < 1:
             raise NotImplementedError("device contexts carry at least one ghost layer")
         self.mpi_construct = mpi_construct
@@ -417,7 +427,9 @@ class _DomainDoubling:
 
 
 class MPIDomainDoublingCommunicator3D(_DomainDoubling):
-    """poisson_solver_3d/UnboundedPoissonSolverMPI3D.py:190-382 on one rank."""
+    """poisson_solver_3d/UnboundedPoissonSolverMPI3D.py:190-382, on one rank or an even number of z-slabs: every
+    rank's interior block goes to rank r // 2 of the same decomposition of the doubled grid, whose
+    ``local_doubled_field`` is (2 nz_local, 2 ny, 2 nx); ranks P / 2 and up hold padding only."""
 
 
 __all__ = [n for n in dir() if n.startswith("gen_")] + [

@@ -237,3 +237,29 @@ def test_advection_flux_eno3_2d(smi, real_t):
     scratch = ctx.zeros(pshape, real_t)
     step_op(field=dfield, advection_flux=scratch, velocity=dvel, dt_by_dx=dt_by_dx)
     assert_close(dfield.get(), want_field, real_t, factor=1.0, what="advection timestep 2d")
+
+
+@pytest.mark.parametrize("nranks,grid,precision", [(2, "16x16x24", "single"), (4, "32x16x16", "single"),
+                                                   (4, "16x32x24", "double"), (8, "32x32x16", "single")])
+def test_fft_and_doubled_domain_types_across_slabs(nranks, grid, precision):
+    """FFTMPI3D (mpi4py-fft's slab layouts: real array divided along z, spectrum along y) and
+    MPIDomainDoublingCommunicator3D across 2, 4 and 8 z-slabs sharing the GPU over the host-staged transport:
+    against scipy.fft.rfftn of the global array, and the reference's solve sequence assembled from the two types
+    against the oracle (tests/_fft_api_ranks_worker.py)."""
+    import os
+    import subprocess
+    import sys
+
+    from test_gpu_slabs import _failure_digest
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["SOPHT_MI_TRANSPORT"] = "host"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(29650 + nranks),
+           os.path.join(root, "tests", "_fft_api_ranks_worker.py"), grid, precision]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, _failure_digest(out)
+    for r in range(nranks):
+        assert f"rank {r} ok" in out.stdout

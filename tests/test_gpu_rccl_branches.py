@@ -64,6 +64,14 @@ def test_row_slab_2d_flow_over_the_rccl_branches(nranks, flow_type, mode, grid):
     _run("_rows_worker_2d.py", nranks, 29900 + nranks, [flow_type, mode] + grid.split())
 
 
+@pytest.mark.parametrize("nranks,grid,precision", [(2, "16x16x24", "single"), (4, "16x32x24", "double"),
+                                                   (8, "32x32x16", "single")])
+def test_fft_and_doubled_domain_types_over_the_rccl_branches(nranks, grid, precision):
+    """FFTMPI3D and MPIDomainDoublingCommunicator3D across z-slabs: the grouped all-to-all of the transform and the
+    ncclSend / ncclRecv pairs of the doubled-domain copies (one send to rank r // 2, two receives on the lower half)."""
+    _run("_fft_api_ranks_worker.py", nranks, 29930 + nranks, [grid, precision])
+
+
 @pytest.mark.parametrize("worker,nranks,args", [
     ("_slab_worker.py", 2, "navier_stokes fused 32x16x32"),
     ("_slab_worker.py", 4, "navier_stokes_with_forcing fused 64x32x64 nofilter"),
