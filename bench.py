@@ -176,6 +176,17 @@ def launch_ranks(n_gpus, argv, timeout_s):
         raise
 
 
+def transpose_chunks(ctx):
+    """z chunks per spectral transpose the library uses on this context (SMI_FFT_TRANSPOSE_CHUNKS or its default)."""
+    import ctypes
+
+    from sopht_mpi_amd import _lib
+
+    value = ctypes.c_int(0)
+    _lib.call("smi_ctx_get_option", ctx.handle, b"transpose_chunks", ctypes.byref(value))
+    return value.value
+
+
 class Watchdog:
     """Multi-rank runs only: a collective that never completes (a rank missing, a link down) would otherwise hold
     every rank and the launcher until somebody kills them.  Each phase gets a deadline; when one passes, the rank
@@ -285,7 +296,7 @@ def main():
         "partition": "1 GPU" if args.gpus == 1 else f"{args.gpus} z-slabs",
         "transport": sim.ctx.transport,
         "rccl_ranks": args.gpus if sim.ctx.transport == "rccl" else 0,
-        "transpose_chunks": int(os.environ.get("SMI_FFT_TRANSPOSE_CHUNKS", "1")) if args.gpus > 1 else None,
+        "transpose_chunks": transpose_chunks(sim.unbounded_poisson_solver.ctx) if args.gpus > 1 else None,
         "poisson_backend": sim.unbounded_poisson_solver.backend,
         # fraction of the HBM peak the step reaches, on the bytes this implementation moves by design
         # (f32: advect + diffuse 9 S + 3 x Poisson 27 S + curl 6 S, S = 4 B per grid point)

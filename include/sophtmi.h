@@ -66,8 +66,10 @@ int smi_sync(smi_ctx* ctx);
  *   "no_fused_advect_diffuse" (SMI_NO_FUSED_ADVECT_DIFFUSE)  1: advection and diffusion as two passes
  *   "fused_split_launch"      (SMI_FUSED_SPLIT_LAUNCH)       1: interior z chunks and outer z chunks as two launches
  *   "fused_zchunk"            (SMI_FUSED_ZCHUNK)             planes per workgroup of the one-pass kernel, 0 = automatic
- *   "transpose_chunks"        (SMI_FFT_TRANSPOSE_CHUNKS)     1, 2 or 4 z chunks per spectral transpose across ranks */
+ *   "transpose_chunks"        (SMI_FFT_TRANSPOSE_CHUNKS)     1, 2 or 4 z chunks per spectral transpose across ranks
+ *                                                            (default: 2 from eight ranks on, 1 below) */
 int smi_ctx_set_option(smi_ctx* ctx, const char* name, int value);
+int smi_ctx_get_option(smi_ctx* ctx, const char* name, int* value);
 
 /* RCCL communicator over the slab ranks.  unique_id: the 128-byte ncclUniqueId made
  * by smi_comm_unique_id on rank 0 and broadcast by the host launcher.  Replaces

@@ -85,7 +85,10 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   c->opt_no_fused = getenv("SMI_NO_FUSED_ADVECT_DIFFUSE") != nullptr;
   c->opt_split_launch = getenv("SMI_FUSED_SPLIT_LAUNCH") != nullptr;
   if (const char* e = getenv("SMI_FUSED_ZCHUNK")) c->opt_fused_zchunk = atoi(e) > 0 ? atoi(e) : 32;
-  c->opt_transpose_chunks = 1;
+  // Two chunks per transpose from eight ranks on: there the transforms and the link time of a step are about equal
+  // and what is exposed is the first forward and the last backward transpose, which chunking halves; with fewer
+  // ranks the links are the bound by a wide margin and chunks only add RCCL groups.
+  c->opt_transpose_chunks = nranks >= 8 ? 2 : 1;
   if (const char* e = getenv("SMI_FFT_TRANSPOSE_CHUNKS")) {
     const int n = atoi(e);
     SMI_REQUIRE(n == 1 || n == 2 || n == 4, "SMI_FFT_TRANSPOSE_CHUNKS=%s: must be 1, 2 or 4", e);
@@ -118,6 +121,22 @@ extern "C" int smi_ctx_set_option(smi_ctx* c, const char* name, int value) {
     c->opt_transpose_chunks = value;
   } else {
     SMI_REQUIRE(false, "smi_ctx_set_option: unknown option '%s'", name);
+  }
+  return 0;
+}
+
+extern "C" int smi_ctx_get_option(smi_ctx* c, const char* name, int* value) {
+  SMI_REQUIRE(c && name && value, "smi_ctx_get_option: null argument");
+  if (!strcmp(name, "no_fused_advect_diffuse")) {
+    *value = c->opt_no_fused;
+  } else if (!strcmp(name, "fused_split_launch")) {
+    *value = c->opt_split_launch;
+  } else if (!strcmp(name, "fused_zchunk")) {
+    *value = c->opt_fused_zchunk;
+  } else if (!strcmp(name, "transpose_chunks")) {
+    *value = c->opt_transpose_chunks;
+  } else {
+    SMI_REQUIRE(false, "smi_ctx_get_option: unknown option '%s'", name);
   }
   return 0;
 }

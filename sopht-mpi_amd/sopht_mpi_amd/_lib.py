@@ -115,6 +115,7 @@ SIGNATURES = {
     "smi_ib_frame_loads": [_p, _p, _p, _p, _p, _i, _i64],
     "smi_set_ordered_spread": [_p, _i],
     "smi_ctx_set_option": [_p, C.c_char_p, _i],
+    "smi_ctx_get_option": [_p, C.c_char_p, C.POINTER(C.c_int)],
     "smi_prof_enable": [_p, _i],
     "smi_prof_reset": [_p],
     "smi_prof_get": [_p, _i, C.c_char_p, C.POINTER(C.c_int64), _dp, _dp],
