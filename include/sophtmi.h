@@ -61,11 +61,16 @@ int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx,
                    int rank, int nranks);
 int smi_ctx_destroy(smi_ctx* ctx);
 int smi_sync(smi_ctx* ctx);
+/* Two contexts of one process (a pencil context and the slab context its Poisson solve runs on) have their own
+ * streams: what has been queued on `other` completes before what is queued on `waiter` afterwards starts, without a
+ * host synchronisation (the reference's calls are synchronous, so it has no counterpart). */
+int smi_ctx_wait_for(smi_ctx* waiter, smi_ctx* other);
 /* Execution switches of a context (no counterpart in the reference; tests and measurements).  smi_ctx_create reads
  * them once from the environment and no entry point consults the environment afterwards:
  *   "no_fused_advect_diffuse" (SMI_NO_FUSED_ADVECT_DIFFUSE)  1: advection and diffusion as two passes
  *   "fused_split_launch"      (SMI_FUSED_SPLIT_LAUNCH)       1: interior z chunks and outer z chunks as two launches
  *   "fused_zchunk"            (SMI_FUSED_ZCHUNK)             planes per workgroup of the one-pass kernel, 0 = automatic
+ *   "check_forcing_support"   (SMI_CHECK_FORCING_SUPPORT)    1: the step verifies a promised forcing box before use
  *   "transpose_chunks"        (SMI_FFT_TRANSPOSE_CHUNKS)     1, 2 or 4 z chunks per spectral transpose across ranks
  *                                                            (default: 2 from eight ranks on, 1 below) */
 int smi_ctx_set_option(smi_ctx* ctx, const char* name, int value);
@@ -375,6 +380,11 @@ int smi_flow_step_ns3d_swap(smi_ctx* ctx, smi_poisson* p, void* vorticity, void*
  * results are those of the full-array operators.  No counterpart in the reference, whose forcing update
  * always sweeps the whole grid. */
 int smi_set_forcing_support(smi_ctx* ctx, const int* lo_zyx, const int* hi_zyx);
+/* The promise checked: number of non-zero cells of `forcing` outside the box promised on ctx (0 without a promise).
+ * With the context option "check_forcing_support" (SMI_CHECK_FORCING_SUPPORT) the step runs this check itself and
+ * fails instead of using a box that does not hold - for callers that write the forcing field through raw pointers
+ * and want their bookkeeping verified.  No counterpart in the reference. */
+int smi_check_forcing_support(smi_ctx* ctx, const void* forcing, long long* outside_nonzero);
 
 /* ---- 2D flow path --------------------------------------------------------------------
  * Operators of UnboundedFlowSimulator2D (simulator/flow/flow_simulators_mpi_2d.py:166-298) on

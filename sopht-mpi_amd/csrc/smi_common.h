@@ -39,6 +39,7 @@ struct smi_ctx {
   hipStream_t stream;
   hipStream_t comm_stream;
   hipEvent_t ev_a, ev_b;
+  hipEvent_t ev_order;  // smi_ctx_wait_for: what another context's stream waits for
   void* red_partials;  // device, double[kRedBlocks]
   double* red_host;    // pinned
   ncclComm_t comm;
@@ -70,6 +71,10 @@ struct smi_ctx {
   int opt_no_fused, opt_split_launch, opt_fused_zchunk;
   // z chunks each spectral transpose of a multi-rank Poisson solve is cut into (SMI_FFT_TRANSPOSE_CHUNKS, 1 / 2 / 4)
   int opt_transpose_chunks;
+  // SMI_CHECK_FORCING_SUPPORT / "check_forcing_support": the fused step verifies a promised forcing box (every cell
+  // outside it must be zero) before it relies on it, and fails if it does not hold; a debugging aid for callers of
+  // smi_set_forcing_support, one extra sweep of the forcing field per step
+  int opt_check_forcing_support;
 };
 constexpr int kUmaxSlots = 64;
 

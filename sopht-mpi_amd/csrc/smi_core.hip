@@ -28,6 +28,7 @@ static int ctx_allocate(smi_ctx* c) {
   SMI_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
   SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+  SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
   SMI_CHECK_HIP(hipMalloc(&c->red_partials, sizeof(double) * (kRedBlocks + 8)));
   SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, sizeof(double) * 8, hipHostMallocDefault));
   SMI_CHECK_HIP(hipMalloc(&c->fac_dev, sizeof(double) * 6 * 64));
@@ -84,6 +85,7 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   // environment switches are read here, once, and never on the step path
   c->opt_no_fused = getenv("SMI_NO_FUSED_ADVECT_DIFFUSE") != nullptr;
   c->opt_split_launch = getenv("SMI_FUSED_SPLIT_LAUNCH") != nullptr;
+  c->opt_check_forcing_support = getenv("SMI_CHECK_FORCING_SUPPORT") != nullptr;
   if (const char* e = getenv("SMI_FUSED_ZCHUNK")) c->opt_fused_zchunk = atoi(e) > 0 ? atoi(e) : 32;
   // Two chunks per transpose from eight ranks on: there the transforms and the link time of a step are about equal
   // and what is exposed is the first forward and the last backward transpose, which chunking halves; with fewer
@@ -112,6 +114,8 @@ extern "C" int smi_ctx_set_option(smi_ctx* c, const char* name, int value) {
     c->opt_no_fused = value != 0;
   } else if (!strcmp(name, "fused_split_launch")) {
     c->opt_split_launch = value != 0;
+  } else if (!strcmp(name, "check_forcing_support")) {
+    c->opt_check_forcing_support = value != 0;
   } else if (!strcmp(name, "fused_zchunk")) {
     SMI_REQUIRE(value >= 0, "smi_ctx_set_option: fused_zchunk %d must not be negative", value);
     c->opt_fused_zchunk = value;
@@ -131,6 +135,8 @@ extern "C" int smi_ctx_get_option(smi_ctx* c, const char* name, int* value) {
     *value = c->opt_no_fused;
   } else if (!strcmp(name, "fused_split_launch")) {
     *value = c->opt_split_launch;
+  } else if (!strcmp(name, "check_forcing_support")) {
+    *value = c->opt_check_forcing_support;
   } else if (!strcmp(name, "fused_zchunk")) {
     *value = c->opt_fused_zchunk;
   } else if (!strcmp(name, "transpose_chunks")) {
@@ -187,9 +193,21 @@ extern "C" int smi_ctx_destroy(smi_ctx* c) {
   if (c->red_host) hipHostFree(c->red_host);
   if (c->ev_a) hipEventDestroy(c->ev_a);
   if (c->ev_b) hipEventDestroy(c->ev_b);
+  if (c->ev_order) hipEventDestroy(c->ev_order);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->comm_stream) hipStreamDestroy(c->comm_stream);
   delete c;
+  return 0;
+}
+
+// Orders the streams of two contexts of one process without a host synchronisation: everything queued on `other` so
+// far completes before anything queued on `waiter` from now on starts.
+extern "C" int smi_ctx_wait_for(smi_ctx* waiter, smi_ctx* other) {
+  SMI_REQUIRE(waiter && other, "smi_ctx_wait_for: null context");
+  if (waiter == other) return 0;
+  SMI_REQUIRE(waiter->device == other->device, "smi_ctx_wait_for: the two contexts live on different devices");
+  SMI_CHECK_HIP(hipEventRecord(other->ev_order, other->stream));
+  SMI_CHECK_HIP(hipStreamWaitEvent(waiter->stream, other->ev_order, 0));
   return 0;
 }
 

@@ -73,6 +73,47 @@ extern "C" int smi_set_forcing_support(smi_ctx* c, const int* lo_zyx, const int*
   return 0;
 }
 
+namespace {
+// counts the non-zero cells of a three-component field outside the padded-index box [lo, hi]
+template <typename T>
+__global__ void __launch_bounds__(256) k_count_outside_box(const T* __restrict__ f, long long vol, int py, int px,
+                                                          int zlo, int zhi, int ylo, int yhi, int xlo, int xhi,
+                                                          unsigned long long* __restrict__ count) {
+  unsigned long long mine = 0;
+  const long long plane = (long long)py * px;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * vol; i += (long long)gridDim.x * blockDim.x) {
+    const long long cell = i % vol;
+    const int z = (int)(cell / plane), y = (int)((cell % plane) / px), x = (int)(cell % px);
+    const bool inside = z >= zlo && z <= zhi && y >= ylo && y <= yhi && x >= xlo && x <= xhi;
+    if (!inside && f[i] != T(0)) ++mine;
+  }
+  if (mine) atomicAdd(count, mine);
+}
+}  // namespace
+
+// The promise of smi_set_forcing_support, verified: *outside_nonzero = number of non-zero cells of `forcing` outside
+// the box currently promised on this context (0 when no promise is set).  Synchronises.
+extern "C" int smi_check_forcing_support(smi_ctx* c, const void* forcing, long long* outside_nonzero) {
+  SMI_REQUIRE(c && forcing && outside_nonzero, "smi_check_forcing_support: null argument");
+  *outside_nonzero = 0;
+  if (!c->fbox_valid) return 0;
+  unsigned long long* count = (unsigned long long*)c->fac_dev;
+  SMI_CHECK(smi_memset_zero(c, count, sizeof(unsigned long long)));
+  const long long n = 3 * (long long)c->vol;
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  SMI_DISPATCH(c, {
+    k_count_outside_box<T><<<blocks, 256, 0, c->stream>>>((const T*)forcing, (long long)c->vol, c->py, c->px, c->fbox_lo[0],
+                                                         c->fbox_hi[0], c->fbox_lo[1], c->fbox_hi[1], c->fbox_lo[2],
+                                                         c->fbox_hi[2], count);
+  });
+  SMI_LAUNCH_CHECK();
+  unsigned long long host = 0;
+  SMI_CHECK_HIP(hipMemcpyAsync(&host, count, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+  SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+  *outside_nonzero = (long long)host;
+  return 0;
+}
+
 static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
                                   void* buffer_vector, void* buffer_scalar, void* forcing, double dt, double nu,
                                   double dx, int penalty_width, const double* fac_lo, const double* fac_hi,
@@ -92,6 +133,14 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
     pref_vel = 0.5 / dx;
   }
   const bool boxed = forcing && c->fbox_valid && c->nranks == 1;
+  if (boxed && c->opt_check_forcing_support) {
+    long long outside = 0;
+    SMI_CHECK(smi_check_forcing_support(c, forcing, &outside));
+    SMI_REQUIRE(outside == 0,
+                "smi_flow_step_ns3d: %lld non-zero forcing cells lie outside the box promised with "
+                "smi_set_forcing_support ([%d..%d] x [%d..%d] x [%d..%d] in z, y, x)",
+                outside, c->fbox_lo[0], c->fbox_hi[0], c->fbox_lo[1], c->fbox_hi[1], c->fbox_lo[2], c->fbox_hi[2]);
+  }
   if (boxed)
     SMI_CHECK(smi_forcing_update_boxed_impl(c, vorticity, forcing, pref_curl));
   else if (forcing)

@@ -46,6 +46,8 @@ SIGNATURES = {
     "smi_ctx_create": [_pp, _i, _i, _i, _i, _i, _i, _i, _i],
     "smi_ctx_destroy": [_p],
     "smi_sync": [_p],
+    "smi_ctx_wait_for": [_p, _p],
+    "smi_check_forcing_support": [_p, _p, C.POINTER(C.c_longlong)],
     "smi_comm_unique_id": [_p],
     "smi_comm_init": [_p, _p],
     "smi_set_exchange_callback": [_p, EXCHANGE_CB, _p],

@@ -308,11 +308,15 @@ class UnboundedPoissonSolverMPI3D:
         pencil, slab = self.pencil_ctx, self.ctx
         work_a, work_b = (as_ptr(w) for w in self._work)
         call("smi_pencil_to_slab", pencil.handle, slab.handle, as_ptr(self._slab_rhs), as_ptr(rhs), ncomp, work_a, work_b)
-        pencil.sync()   # the two contexts have their own streams
+        # the two contexts have their own streams: events order them, the host does not wait
+        call("smi_ctx_wait_for", slab.handle, pencil.handle)
         call(entry, self.handle, as_ptr(self._slab_sol), as_ptr(self._slab_rhs))
-        slab.sync()
+        call("smi_ctx_wait_for", pencil.handle, slab.handle)
         call("smi_slab_to_pencil", pencil.handle, slab.handle, as_ptr(solution), as_ptr(self._slab_sol), ncomp, work_a,
              work_b)
+        # the next redistribution reuses the work arrays and the slab arrays on the pencil stream; the slab stream
+        # must not run ahead of it with the next solve's input
+        call("smi_ctx_wait_for", slab.handle, pencil.handle)
 
     def __del__(self):
         try:

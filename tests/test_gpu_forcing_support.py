@@ -148,3 +148,35 @@ def test_step_gathers_the_velocity_maximum(smi, real_t, free_stream):
     sim.velocity_field[...] = 0  # a host write
     dt0 = sim.compute_stable_timestep()
     assert dt0 == pytest.approx(min(sim.CFL * sim.dx / 1e-4, 0.9 * sim.dx**2 / 6 / (1e-3 + 1e-4)), rel=1e-5)
+
+
+def test_a_promise_that_does_not_hold_is_caught_when_checking_is_on(smi):
+    """The contract of smi_set_forcing_support is the caller's to keep; with the context option
+    "check_forcing_support" the step verifies the box first and refuses one that does not hold."""
+    from sopht_mpi_amd._lib import SophtMIError, call
+
+    real_t = np.float32
+    sim = _sim(real_t)
+    fs = [1.0, 0.0, 0.0]
+    sim.vorticity_field[...] = _blob(sim, real_t)
+    sim.compute_flow_velocity(free_stream_velocity=fs)
+    forcing = np.zeros(sim.eul_grid_forcing_field.shape, dtype=real_t)
+    forcing[:, 8:12, 8:12, 8:12] = 0.25
+    forcing[1, 20, 3, 30] = 1e-3                       # one cell outside the box about to be promised
+    sim.eul_grid_forcing_field[...] = forcing
+    box = ((7, 7, 7), (12, 12, 12))
+    lo, hi = (C.c_int * 3)(*box[0]), (C.c_int * 3)(*box[1])
+    call("smi_set_forcing_support", sim.ctx.handle, lo, hi)
+    outside = C.c_longlong(-1)
+    call("smi_check_forcing_support", sim.ctx.handle, sim.eul_grid_forcing_field.tracked_ptr(), C.byref(outside))
+    assert outside.value == 1
+    call("smi_ctx_set_option", sim.ctx.handle, b"check_forcing_support", 1)
+    sim.eul_grid_forcing_field._alloc.support = box
+    with pytest.raises(SophtMIError, match="outside the box"):
+        sim.time_step(dt=2e-3, free_stream_velocity=fs)
+    # the same box with the stray cell removed passes the check and steps like the full sweep
+    forcing[1, 20, 3, 30] = 0
+    sim.eul_grid_forcing_field[...] = forcing
+    sim.eul_grid_forcing_field._alloc.support = box
+    sim.time_step(dt=2e-3, free_stream_velocity=fs)
+    assert not sim.eul_grid_forcing_field.get().any()

@@ -109,3 +109,28 @@ def test_rccl_communicator_initialises(smi):
     call("smi_allreduce_f64", h, out, 1, 0)  # one rank: the value comes back unchanged
     assert out[0] == 3.5
     assert lib.smi_ctx_destroy(h) == 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its two ranks itself (a child
+    torch.distributed.run), relays rank 0's JSON line and returns the child's status.  The ranks share the GPU over
+    the host-staged transport, so the line is marked invalid as a measurement."""
+    import json
+
+    env = dict(os.environ)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    env["SOPHT_MI_TRANSPORT"] = "host"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--rehearse-on-host-transport"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, _failure_digest(out)
+    lines = [line for line in out.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["config"]["partition"] == "2 z-slabs"
+    assert rec["config"]["transpose_chunks"] == 1 and "invalid" in rec and rec["value"] > 0
+    # a rank count the launcher did not start is refused, not silently run on one rank
+    env["WORLD_SIZE"] = "1"
+    bad = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
