@@ -310,6 +310,12 @@ constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per 
 #ifndef SMI_FFT_ZCOLS
 #define SMI_FFT_ZCOLS 0
 #endif
+// mixed plans with a middle radix above this run the z convolution in its lean form (see k_fft_z_conv).  Measured with
+// 6 (the 192-, 320- and 384-point plans in the full form, which then spills or exceeds 128 registers): z convolution
+// 2.42 against 1.95 ms at 384^3, 1.29 against 1.19 ms at 320^3, 0.29 against 0.22 ms at 192^3, so every mixed plan is lean
+#ifndef SMI_FFT_LEAN_ABOVE
+#define SMI_FFT_LEAN_ABOVE 0
+#endif
 // Row tiles one workgroup of the x kernels walks over (the twiddle set-up is then paid once for all of them) and
 // rows per tile.  Measured at 512^3 (512-point plan): two tiles against one take x_fwd from 0.95 to 0.93 ms and x_inv
 // from 0.98 to 0.94 ms; eight rows per tile instead of four change nothing.  The mixed plans keep one tile (two cost
@@ -836,7 +842,7 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
   // do not fit 128 registers with the Green's values of both parities held across tiles and the
   // next column requested two transforms ahead: they reload the former per tile and request the
   // latter one transform ahead.
-  constexpr bool LEAN = !Plan<LG>::POW2;
+  constexpr bool LEAN = !Plan<LG>::POW2 && Plan<LG>::RM > SMI_FFT_LEAN_ABOVE;
   int ct, kyc, k;
   if (!col_tile<Cfg::PF>(G, ct, kyc, k)) return;
   const int col = G.colbase + ct * TS + t;
