@@ -318,27 +318,41 @@ constexpr int kMaxThreads = 1024;  // FFT kernels: one work item (8 points) per 
 #endif
 // Row tiles one workgroup of the x kernels walks over (the twiddle set-up is then paid once for all of them) and
 // rows per tile.  Measured at 512^3 (512-point plan): two tiles against one take x_fwd from 0.95 to 0.93 ms and x_inv
-// from 0.98 to 0.94 ms; eight rows per tile instead of four change nothing.  The mixed plans keep one tile (two cost
-// the 192-point plan's x_inv a quarter when its rows were half as long).
+// from 0.98 to 0.94 ms; eight rows per tile instead of four, or one or two rows and four or eight tiles, change nothing
+// or cost 1-5 %.  The mixed plans of up to 64 lanes per sequence, whose radix-8 stages leave a quarter or more of those
+// lanes idle, want the opposite: ONE wave per workgroup (a single row, two for the 32-lane 192-point plan; the barriers
+// of its exchanges then synchronise nobody) walking over four (forward) or eight (inverse) rows.  Measured at 384^3
+// against eight rows per tile and one tile: x_fwd 0.61 -> 0.46 ms, x_inv 0.56 -> 0.38 ms (four rows x two tiles: 0.49 /
+// 0.49; two rows x four tiles: 0.45 / 0.45); at 320^3 0.33 / 0.34 -> 0.28 / 0.22; at 192^3 0.069 / 0.083 -> 0.051 / 0.061.
+// The 640- and 768-point plans (80 and 96 lanes per sequence, so a row is not one wave) keep four rows and one tile:
+// single rows measured 2.96 / 2.52 against 2.48 / 2.57 ms at 640^3 and 4.24 / 5.28 against 5.15 / 4.75 ms at 768^3.
 #ifndef SMI_FFT_XT_FWD
 #define SMI_FFT_XT_FWD 2
 #endif
 #ifndef SMI_FFT_XT_INV
 #define SMI_FFT_XT_INV 2
 #endif
+#ifndef SMI_FFT_XT_FWD_MIXED
+#define SMI_FFT_XT_FWD_MIXED 4
+#endif
+#ifndef SMI_FFT_XT_INV_MIXED
+#define SMI_FFT_XT_INV_MIXED 8
+#endif
 #ifndef SMI_FFT_XROWS
 #define SMI_FFT_XROWS 4
 #endif
 template <int LG>
 constexpr int x_tiles(bool fwd) {
-  return fwd ? ((Plan<LG>::POW2 && LG >= 8) ? SMI_FFT_XT_FWD : 1) : ((Plan<LG>::POW2 && LG >= 8) ? SMI_FFT_XT_INV : 1);
+  if (!Plan<LG>::POW2) return Plan<LG>::TPS <= 64 ? (fwd ? SMI_FFT_XT_FWD_MIXED : SMI_FFT_XT_INV_MIXED) : 1;
+  return LG >= 8 ? (fwd ? SMI_FFT_XT_FWD : SMI_FFT_XT_INV) : 1;
 }
 #ifndef SMI_FFT_COLS_F32
 #define SMI_FFT_COLS_F32 16
 #endif
 // Sequences per tile.  Column passes want >= 16 (f32) / 8 (f64) so that every row of the tile
 // is a whole 128-byte line; TS * L / 8 threads, at most 1024.
-constexpr int tile_seqs(int L, int tps, bool f32, bool rows, int want_cols = 0) {
+constexpr int tile_seqs(int L, int tps, bool f32, bool rows, int want_cols = 0, bool pow2 = true) {
+  if (rows && !pow2 && tps <= 64) return 64 / tps;  // one wave per row tile
   int want = rows ? SMI_FFT_XROWS : (want_cols ? want_cols : (f32 ? SMI_FFT_COLS_F32 : 8));
   int ts = want;
   while (ts * L < 2048) ts *= 2;
@@ -644,7 +658,7 @@ template <typename T, int LG, bool ROWS, int WANT_COLS = 0>
 struct TileCfg {
   static constexpr int L = Plan<LG>::L, L8 = Plan<LG>::L8;
   static constexpr int TPS = Plan<LG>::TPS;
-  static constexpr int TS = tile_seqs(L, TPS, sizeof(T) == 4, ROWS, WANT_COLS), NT = TS * TPS;
+  static constexpr int TS = tile_seqs(L, TPS, sizeof(T) == 4, ROWS, WANT_COLS, Plan<LG>::POW2), NT = TS * TPS;
   static constexpr int PITCH = L + L / 8 + 1;                            // row layout
   // waves per SIMD the register allocation must allow: single precision column kernels of 512
   // lanes keep to 128 registers, like those of 1024, so that two of them fit a CU
