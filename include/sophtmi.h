@@ -250,11 +250,21 @@ int smi_poisson_create(smi_poisson** out, smi_ctx* ctx, int global_nz, int globa
                        double dx, double x_range, int backend);
 /* 1 when smi_poisson_create would accept this global grid on `nranks` slabs with this back end, else 0: the
  * rocFFT back end takes any grid on one rank; the pruned one needs nx, ny and nz to be powers of two from 8
- * to 2048 or one of 192, 384, 768.  No counterpart in the reference (mpi4py-fft plans any size). */
+ * to 2048 or one of 192, 320, 384, 640, 768.  No counterpart in the reference (mpi4py-fft plans any size). */
 int smi_poisson_supports(int global_nz, int global_ny, int global_nx, int nranks, int backend);
 int smi_poisson_destroy(smi_poisson* p);
 int smi_poisson_solve(smi_poisson* p, void* solution, const void* rhs);
 int smi_poisson_vector_solve(smi_poisson* p, void* solution, const void* rhs);
+/* A pencil decomposition solves through the z-slab decomposition of the same grid, as the reference's solver moves
+ * its fields between the grid's and the transform's decomposition (UnboundedPoissonSolverMPI3D.py:190-382).
+ * smi_poisson_set_pencil_route names, for a solver created on the slab context, the pencil context of the same rank,
+ * two three-component slab arrays (right-hand side, solution) and two work arrays of 3 * (pencil interior cells)
+ * elements; they stay the caller's, and a null `pencil` withdraws the route.  smi_poisson_pencil_solve then solves
+ * for ncomp = 1 or 3 components of pencil fields (smi_pencil_to_slab, the solve, smi_slab_to_pencil, ordered by
+ * events between the two contexts' streams), and smi_flow_step_ns3d accepts the pencil context with that solver. */
+int smi_poisson_set_pencil_route(smi_poisson* p, smi_ctx* pencil, void* slab_rhs, void* slab_sol, void* work_a,
+                                 void* work_b);
+int smi_poisson_pencil_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp);
 /* smi_poisson_solve for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same kernels and
  * bit-identical results, but the spectral work buffers come from a fixed 64 MiB array inside the library

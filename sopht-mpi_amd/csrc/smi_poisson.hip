@@ -273,6 +273,8 @@ extern "C" int smi_poisson_create(smi_poisson** out, smi_ctx* ctx, int global_nz
   p->x_range = x_range;
   p->rocfft = nullptr;
   p->pruned = nullptr;
+  p->pencil = nullptr;
+  p->route_rhs = p->route_sol = p->route_work[0] = p->route_work[1] = nullptr;
   int rc = backend == SMI_POISSON_ROCFFT ? rocfft_create(p) : smi_pruned_create(p);
   if (rc != 0) {
     if (backend == SMI_POISSON_ROCFFT) rocfft_destroy(p); else smi_pruned_destroy(p);
@@ -320,6 +322,57 @@ extern "C" int smi_poisson_vector_solve(smi_poisson* p, void* solution, const vo
   for (int k = 0; k < 3; ++k)
     SMI_CHECK(rocfft_solve(p, (char*)solution + k * stride, (const char*)rhs + k * stride));
   return 0;
+}
+
+// A pencil decomposition solves through the z-slab decomposition of the same grid (the reference's solver moves its
+// fields between the grid's and the transform's decomposition likewise, UnboundedPoissonSolverMPI3D.py:190-382).
+// The route names the pencil context, two three-component slab arrays (right-hand side, solution) and two work arrays
+// of 3 * (pencil interior cells) elements; all stay the caller's.  Null pencil withdraws it.
+extern "C" int smi_poisson_set_pencil_route(smi_poisson* p, smi_ctx* pencil, void* slab_rhs, void* slab_sol,
+                                            void* work_a, void* work_b) {
+  SMI_REQUIRE(p, "smi_poisson_set_pencil_route: null solver");
+  if (!pencil) {
+    p->pencil = nullptr;
+    return 0;
+  }
+  SMI_REQUIRE(slab_rhs && slab_sol && work_a && work_b && slab_rhs != slab_sol && work_a != work_b,
+              "smi_poisson_set_pencil_route: four distinct arrays are needed");
+  SMI_REQUIRE(pencil != p->ctx && pencil->device == p->ctx->device && pencil->rank == p->ctx->rank &&
+                  pencil->nranks == p->ctx->nranks && pencil->dtype == p->ctx->dtype,
+              "smi_poisson_set_pencil_route: the pencil context does not describe the solver's rank");
+  p->pencil = pencil;
+  p->route_rhs = slab_rhs;
+  p->route_sol = slab_sol;
+  p->route_work[0] = work_a;
+  p->route_work[1] = work_b;
+  return 0;
+}
+
+// -del^2 solution = rhs for ncomp (1 or 3) components of fields of the routed pencil context: right-hand side to
+// slabs, solve, solution back to pencils.  The two contexts have their own streams; events order them and the host
+// does not wait.
+extern "C" int smi_poisson_pencil_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp) {
+  SMI_REQUIRE(p && solution && rhs && (ncomp == 1 || ncomp == 3), "smi_poisson_pencil_solve: bad argument");
+  SMI_REQUIRE(p->pencil, "smi_poisson_pencil_solve: no pencil route set (smi_poisson_set_pencil_route)");
+  smi_ctx *pen = p->pencil, *slab = p->ctx;
+  SMI_CHECK(smi_pencil_to_slab(pen, slab, p->route_rhs, rhs, ncomp, p->route_work[0], p->route_work[1]));
+  SMI_CHECK(smi_ctx_wait_for(slab, pen));
+  if (ncomp == 3)
+    SMI_CHECK(smi_poisson_vector_solve(p, p->route_sol, p->route_rhs));
+  else
+    SMI_CHECK(smi_poisson_solve(p, p->route_sol, p->route_rhs));
+  SMI_CHECK(smi_ctx_wait_for(pen, slab));
+  SMI_CHECK(smi_slab_to_pencil(pen, slab, solution, p->route_sol, ncomp, p->route_work[0], p->route_work[1]));
+  // the next redistribution reuses the work and slab arrays on the pencil stream: the slab stream must not run
+  // ahead of it with the next solve's input
+  return smi_ctx_wait_for(slab, pen);
+}
+
+int smi_poisson_vector_solve_for(smi_ctx* c, smi_poisson* p, void* solution, const void* rhs) {
+  SMI_REQUIRE(c && p, "Poisson solve: null argument");
+  if (c == p->ctx) return smi_poisson_vector_solve(p, solution, rhs);
+  SMI_REQUIRE(c == p->pencil, "Poisson solve: the solver serves neither this context nor a pencil context routed to it");
+  return smi_poisson_pencil_solve(p, solution, rhs, 3);
 }
 
 extern "C" size_t smi_poisson_greens_size(smi_poisson* p) {

@@ -30,6 +30,9 @@ struct Geo {
   // the planes the vorticity update writes there, [g, pz - g - 1], plus the ghost plane next to a neighbouring
   // rank (what that rank computes for its own edge plane, needed by the diffusion stencil of this rank's edge)
   int za_lo, za_hi;
+  // the same across an inner y face of a pencil: the ghost row there is the neighbour's FACE row (on_face in its
+  // frame), so the one-pass kernel applies the face part of the update set to it; -1 next to a physical face
+  int yf_lo, yf_hi;
 };
 
 Geo make_geo(const smi_ctx* c) {
@@ -48,6 +51,8 @@ Geo make_geo(const smi_ctx* c) {
   G.yhi_c = c->py - c->g - 1 - (c->phys_yhi ? 1 : 0);
   G.za_lo = c->g - (c->phys_zlo ? 0 : 1);
   G.za_hi = c->pz - c->g - 1 + (c->phys_zhi ? 0 : 1);
+  G.yf_lo = c->phys_ylo ? -1 : c->g - 1;
+  G.yf_hi = c->phys_yhi ? -1 : c->py - c->g;
   return G;
 }
 
@@ -676,13 +681,16 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
   T* tb = lds;              // b_x, b_y, b_z of the plane ahead
   T* tw = lds + 3 * comp;   // w*_x, w*_y, w*_z of the current plane
   const int off = (ry + 1) * S.pitch + 4 + 4 * rxl;
-  unsigned mA = 0, mB = 0;  // per cell of the vector: in the sets A (z-dependent) and B of the update set
+  // per cell of the vector: in the sets A (z-dependent) and B of the update set (bits 0-3), and, in bits 8-11 of mA,
+  // in the rows and columns of the diffusion set D (the same as A except on the inner y faces of a pencil)
+  unsigned mA = 0, mB = 0;
   if (in_arr) {
-    const bool yc = in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
+    const bool yc = in_core(y, G.py, G.g), ye = in_ext(y, G.py), yd = in_core_y(G, y);
+    const bool yf = on_face(y, G.py, G.g) || y == G.yf_lo || y == G.yf_hi;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
-      mA |= (unsigned)(yc && xc) << e;
+      mA |= ((unsigned)(yc && xc) << e) | ((unsigned)(yd && xc) << (8 + e));
       mB |= (unsigned)((yf && xc) || (ye && xf)) << e;
     }
   }
@@ -750,7 +758,7 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
     {
       // output of plane k
       if (own && k >= z0) {
-        const unsigned d = (k >= G.zlo_c && k <= G.zhi_c) ? mA : 0u;
+        const unsigned d = (k >= G.zlo_c && k <= G.zhi_c) ? mA >> 8 : 0u;
         const long long zo = (long long)k * G.plane + q;
         const Pack<T, 4>* cur3[3] = {&Wk.x, &Wk.y, &Wk.z};
         const Pack<T, 4>* prv3[3] = {&Zm.x, &Zm.y, &Zm.z};
@@ -1173,9 +1181,9 @@ __global__ void __launch_bounds__(kBlock) k_filter_pass(T* __restrict__ flux, co
 // directional pass L_a g = 0.25 (-g(+1) - g(-1) + 2 g) is taken on D and is 0 elsewhere, exactly
 // as the three passes above leave it (so the intermediate fields vanish outside D when the next
 // pass reads them).  F2 = Ly(Lx f) of a plane only needs f of that plane, so the kernel marches
-// along z with F2 of the planes behind, at and ahead in registers.  Planes one past a rank
+// along z with F2 of the planes behind, at and ahead in registers.  Planes (and, in a pencil, rows) one past a rank
 // boundary count as inside for the intermediate fields (there the neighbour rank computes them
-// from the same exchanged values); [zlo_e, zhi_e] is that extended range.
+// from the same exchanged values); [zlo_e, zhi_e] and [ylo_e, yhi_e] are those extended ranges.
 template <typename T, int V>
 __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, const T* __restrict__ f, Geo G,
                                                         int zchunk, int zlo_e, int zhi_e) {
@@ -1191,8 +1199,10 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
     xc[e] = in_core(x0 + e, G.px, G.g);
     anyx |= xc[e];
   }
-  const bool yc = in_core(y, G.py, G.g);
-  const bool ycm = in_core(y - 1, G.py, G.g), ycp = in_core(y + 1, G.py, G.g);
+  // rows of D, and the rows whose Lx the y pass may read: D plus the ghost row across an inner y face of a pencil
+  const bool yc = in_core_y(G, y);
+  const int ylo_e = G.ylo_c - (G.yf_lo >= 0 ? 1 : 0), yhi_e = G.yhi_c + (G.yf_hi >= 0 ? 1 : 0);
+  const bool ycm = y - 1 >= ylo_e && y - 1 <= yhi_e, ycp = y + 1 >= ylo_e && y + 1 <= yhi_e;
   const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
   const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
   if (!(yc && anyx) || zs > ze) {
@@ -1615,10 +1625,11 @@ static int fused_zchunk(const smi_ctx* c, int tiles_per_plane) {
 
 // out = advection update followed by the diffusion timestep of `vorticity`, in one pass (k_advect_diffuse).
 // *ran = 0 and nothing is launched when this context is not served by the fused kernel (rows that are not whole
-// 4-element vectors; fewer than two ghost layers across ranks; pencils): the caller then runs the two operators one
+// 4-element vectors; fewer than two ghost layers across ranks): the caller then runs the two operators one
 // after the other.
-// Across ranks the kernel needs u and w on BOTH ghost planes next to a neighbour (the advected vorticity of the
-// neighbour's edge plane is formed here from them, see Geo::za_lo), which one exchange of depth 2 delivers, in place
+// Across ranks the kernel needs u and w on BOTH ghost planes (and, in a pencil, ghost rows) next to a neighbour (the
+// advected vorticity of the neighbour's edge plane or row is formed here from them, see Geo::za_lo and Geo::yf_lo),
+// which one exchange of depth 2 delivers, in place
 // of the two exchanges of depth 1 of the two-pass path.  That exchange runs on the communication stream while the
 // chunks of planes that are out of reach of the ghost planes are already being computed; the first and the last
 // chunk follow once it has arrived.
@@ -1628,9 +1639,6 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   SMI_REQUIRE(out != velocity && out != vorticity, "advection-diffusion: output and input must not alias");
   if (c->opt_no_fused) return 0;
   if (smi_multi_rank(c) && c->g < 2) return 0;
-  // across an inner y face the advected vorticity of the neighbour's edge row would have to be formed here as it
-  // is for z (Geo::za_lo); a pencil runs the two operators one after the other instead
-  if (c->nranks_y > 1) return 0;
   bool aligned = false;
   FusedShape S;
   bool shaped = false;
@@ -1675,7 +1683,8 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   // a chunk reads planes z0 - 2 .. z1 + 1: only the first and the last one can reach a ghost plane when both of
   // them are at least g + 2 planes long (the last one is the remainder of the division)
   const int last_chunk = c->pz - (nchunks - 1) * zchunk;
-  const bool overlap = !c->exchange_cb && nchunks >= 3 && zchunk >= c->g + 2 && last_chunk >= c->g + 2;
+  // (the ghost rows of a pencil's y faces reach every chunk: no overlap there)
+  const bool overlap = !c->exchange_cb && c->nranks_y == 1 && nchunks >= 3 && zchunk >= c->g + 2 && last_chunk >= c->g + 2;
   auto exchange = [&]() -> int {
     if (!overlap) return smi_halo_exchange2_impl(c, velocity, 3, vorticity, 3);
     // No RCCL call may be issued on c->stream while this exchange is pending on the communication stream (one
@@ -1830,7 +1839,7 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
   G.zhi_c = c->pz - c->g - 1 - (c->phys_zhi ? w : 0);
   G.ylo_c = c->g + (c->phys_ylo ? w : 0);
   G.yhi_c = c->py - c->g - 1 - (c->phys_yhi ? w : 0);
-  if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1 && w == 1 && c->nranks_y == 1) {
+  if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1 && w == 1) {
     // one fused pass into the scratch field, then back (the scratch fields hold one component)
     const size_t stride = c->vol * smi_elem_size(c);
     for (int k = 0; k < ncomp; ++k) {

@@ -1,6 +1,7 @@
 // One Navier-Stokes flow step sequenced inside the library (flow_simulators_mpi_3d.py:395-424),
 // so that the host pays one call per step instead of one per operator.
 #include "smi_common.h"
+#include "smi_poisson.h"
 #include "smi_prof.h"
 
 static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity, void* stream_func,
@@ -17,8 +18,10 @@ static int flow_step(smi_ctx* c, smi_poisson* p, void* vorticity, void* velocity
                      int penalty_width, const double* fac_lo, const double* fac_hi, const double* free_stream,
                      int filter_order, int filter_type, int* result_in_buffer) {
   SMI_REQUIRE(c, "smi_flow_step_ns3d: null context");
-  SMI_REQUIRE(c->nranks_y == 1,
-              "the one-call flow step serves z-slabs; a pencil decomposition runs the operators one by one");
+  SMI_REQUIRE(p, "smi_flow_step_ns3d: null solver");
+  SMI_REQUIRE(p->ctx == c || p->pencil == c,
+              "smi_flow_step_ns3d: the Poisson solver belongs to another context (a pencil decomposition routes "
+              "its solver with smi_poisson_set_pencil_route)");
   const int saved = c->halo_depth;
   const bool shallow = filter_order == 0 || (filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE);
   if (shallow) c->halo_depth = 1;
@@ -179,7 +182,7 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
     }
   }
   SMI_CHECK(smi_penalise_boundary(c, w_new, 3, penalty_width, fac_lo, fac_hi));
-  SMI_CHECK(smi_poisson_vector_solve(p, stream_func, w_new));
+  SMI_CHECK(smi_poisson_vector_solve_for(c, p, stream_func, w_new));
   // curl and the free stream in one pass over the velocity array
   SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream, /*track_max=*/true));
   if (boxed) {

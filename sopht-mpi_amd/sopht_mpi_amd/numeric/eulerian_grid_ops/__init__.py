@@ -285,6 +285,9 @@ class UnboundedPoissonSolverMPI3D:
         call("smi_poisson_create", C.byref(h), self.ctx.handle, int(grid_size_z), int(grid_size_y),
              int(grid_size_x), float(self.dx), float(x_range), names[backend])
         self.handle, self.backend = h, backend
+        if self.pencil_ctx is not None:
+            call("smi_poisson_set_pencil_route", h, self.pencil_ctx.handle, as_ptr(self._slab_rhs),
+                 as_ptr(self._slab_sol), as_ptr(self._work[0]), as_ptr(self._work[1]))
 
     @staticmethod
     def backend_supports(backend, grid_size_z, grid_size_y, grid_size_x, nranks=1):
@@ -295,28 +298,19 @@ class UnboundedPoissonSolverMPI3D:
     def solve(self, solution_field, rhs_field):
         """-del^2(solution_field) = rhs_field, unbounded domain (:133-167)."""
         if self.pencil_ctx is not None:
-            return self._solve_through_slabs("smi_poisson_solve", solution_field, rhs_field, 1)
+            return self._solve_through_slabs(solution_field, rhs_field, 1)
         call("smi_poisson_solve", self.handle, as_ptr(solution_field), as_ptr(rhs_field))
 
     def vector_field_solve(self, solution_vector_field, rhs_vector_field):
         """:169-187."""
         if self.pencil_ctx is not None:
-            return self._solve_through_slabs("smi_poisson_vector_solve", solution_vector_field, rhs_vector_field, 3)
+            return self._solve_through_slabs(solution_vector_field, rhs_vector_field, 3)
         call("smi_poisson_vector_solve", self.handle, as_ptr(solution_vector_field), as_ptr(rhs_vector_field))
 
-    def _solve_through_slabs(self, entry, solution, rhs, ncomp):
-        pencil, slab = self.pencil_ctx, self.ctx
-        work_a, work_b = (as_ptr(w) for w in self._work)
-        call("smi_pencil_to_slab", pencil.handle, slab.handle, as_ptr(self._slab_rhs), as_ptr(rhs), ncomp, work_a, work_b)
-        # the two contexts have their own streams: events order them, the host does not wait
-        call("smi_ctx_wait_for", slab.handle, pencil.handle)
-        call(entry, self.handle, as_ptr(self._slab_sol), as_ptr(self._slab_rhs))
-        call("smi_ctx_wait_for", pencil.handle, slab.handle)
-        call("smi_slab_to_pencil", pencil.handle, slab.handle, as_ptr(solution), as_ptr(self._slab_sol), ncomp, work_a,
-             work_b)
-        # the next redistribution reuses the work arrays and the slab arrays on the pencil stream; the slab stream
-        # must not run ahead of it with the next solve's input
-        call("smi_ctx_wait_for", slab.handle, pencil.handle)
+    def _solve_through_slabs(self, solution, rhs, ncomp):
+        """Right-hand side to slabs, solve, solution back to pencils: one library call over the route set at
+        construction (events order the two contexts' streams; the host does not wait)."""
+        call("smi_poisson_pencil_solve", self.handle, as_ptr(solution), as_ptr(rhs), ncomp)
 
     def __del__(self):
         try:

@@ -73,9 +73,6 @@ class UnboundedFlowSimulatorBase:
         """Topology -> geometry -> fields -> operators -> stage list."""
         self.mpi_construct, self.mpi_ghost_exchange_communicator = self._make_topology()
         self.ctx = self.mpi_ghost_exchange_communicator.ctx
-        if self.mpi_construct.size > 1 and self.grid_dim == 3 and self.mpi_construct.grid_topology[1] > 1:
-            # the one-call step serves z-slabs; a pencil decomposition runs the reference's operator sequence
-            self.fused_step = False
         self._derive_geometry()
         self._allocate_fields()
         self._build_operators(dict(mpi_construct=self.mpi_construct, real_t=self.real_t,

@@ -80,6 +80,9 @@ if flow_type == "navier_stokes_with_forcing":
     ref = oib.VirtualBoundaryForcing(-2e2 * float(gpu.dx) ** 2, -1e1 * float(gpu.dx) ** 2, 3, cpu.dx, pos.shape[1], g,
                                      eul_real_t=real_t)
 
+from sopht_mpi_amd import _lib  # noqa: E402
+
+_lib.call("smi_prof_enable", gpu.ctx.handle, 1)
 interactor_ms = []
 for step in range(4):
     dt = cpu.compute_stable_timestep(dt_prefac=0.5)
@@ -109,6 +112,11 @@ for step in range(4):
     comm.gather_local_vector_field(got_w, gpu.vorticity_field)
     comm.gather_local_vector_field(got_u, gpu.velocity_field)
     if rank == 0:
+        if os.environ.get("SMI_TEST_SHOW_WORST"):
+            err = np.abs(got_w - cpu.vorticity_field[inner])
+            order = np.argsort(err.ravel())[::-1][:12]
+            print("worst cells (comp, z, y, x):", [tuple(int(v) for v in np.unravel_index(i, err.shape)) for i in order],
+                  [float(err.ravel()[i]) for i in order], flush=True)
         assert_close(got_w, cpu.vorticity_field[inner], real_t, factor=1.0 + 0.5 * step, what=f"vorticity step {step}")
         assert_close(got_u, cpu.velocity_field[inner], real_t, factor=1.0 + 0.5 * step, what=f"velocity step {step}")
 if interactor is not None:
@@ -120,6 +128,10 @@ if interactor is not None:
         assert_close(interactor.global_lag_grid_position_mismatch_field, ref.lag_position_mismatch, np.float32,
                      what="position mismatch after nodes changed slabs")
         print(f"host ms per interactor() call at {size} ranks: " + " ".join(f"{t:.2f}" for t in interactor_ms))
+if fused and (n[2] + 2 * g) % 4 == 0:
+    # the one-call step took the one-pass advection + diffusion kernel on every step (slabs and pencils alike)
+    launched = _lib.prof_collect(gpu.ctx).get("fused_advect_diffuse", {"launches": 0})["launches"]
+    assert launched >= 4, f"one-pass advection + diffusion kernel launched {launched} times in 4 steps"
 mv = gpu.get_max_vorticity()
 assert abs(float(mv) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(float(cpu.get_max_vorticity()))
 world.barrier()

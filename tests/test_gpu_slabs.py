@@ -39,6 +39,13 @@ def _failure_digest(out):
     (4, "navier_stokes_with_forcing", "unfused", "64x32x64 nofilter pencil"),
     (8, "navier_stokes_with_forcing", "unfused", "64x64x64 pencil"),
     (2, "navier_stokes_with_forcing", "unfused", "32x32x32 yslab"),
+    # the one-call step on pencils: the one-pass advection + diffusion forms the neighbour's face row across the inner
+    # y faces, the Poisson solve is routed through the slab decomposition inside the library
+    (4, "navier_stokes", "fused", "32x32x32 pencil"),
+    (4, "navier_stokes_with_forcing", "fused", "64x32x64 pencil"),
+    (4, "navier_stokes_with_forcing", "fused", "64x32x64 nofilter pencil"),
+    (8, "navier_stokes_with_forcing", "fused", "64x64x64 pencil"),
+    (2, "navier_stokes_with_forcing", "fused", "32x32x32 yslab"),
 ])
 def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
     _slab_run(nranks, flow_type, mode, grid, chunks=1)
