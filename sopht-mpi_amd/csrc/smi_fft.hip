@@ -366,12 +366,15 @@ constexpr int tile_seqs(int L, int tps, bool f32, bool rows, int want_cols = 0, 
 // tile.  Row passes: one padded row per sequence, lds[t * PITCH + pos + pos / 8], lanes run
 // along the work items of a sequence; the pos / 8 skew spreads the radix-8 strided writes of
 // the autosort stages over the banks.
-template <int TSP>
+// TPS_: lanes per sequence of the kernel that uses the layout (the mixed plans deal their middle-stage items by it).
+template <int TSP, int TPS_>
 struct ColLayout {
+  static constexpr int TPS = TPS_;
   static constexpr __host__ __device__ __forceinline__ int idx(int pos, int t) { return pos * TSP + t; }
 };
-template <int PITCH>
+template <int PITCH, int TPS_>
 struct RowLayout {
+  static constexpr int TPS = TPS_;
   static constexpr __host__ __device__ __forceinline__ int idx(int pos, int t) { return t * PITCH + pos + (pos >> 3); }
 };
 
@@ -515,12 +518,17 @@ __device__ __forceinline__ void dft_mid(Cx<T> (&x)[12]) {
 // Radix-8 stage on work items u < L/8 (no twiddles: Ns = 1), exchange, radix-R stage on
 // items j < 64 (item j owns j + 64 r, twiddle w_{8R}^{r (j mod 8)}, writes (j - k) R + k + 8 q),
 // exchange, radix-8 stage with twiddles w_L^{m u}.  Every lane takes both barriers.
+// The 64 middle-stage items of a sequence are dealt to its LAY::TPS lanes: lane u takes items u, u + TPS, ... below
+// 64 (one each with 64 or more lanes; two each with 32; with L/8 = 40 or 48 lanes - no lane idle in the radix-8
+// stages - the first 24 or 16 lanes take a second one).
 template <int SIGN, int LG, typename LAY, typename T, bool PP>
 __device__ __forceinline__ void fft_run_mixed(Cx<T> (&v)[8], TileSel<T, PP>& sel, int t, int u,
                                               const Twiddles<T, LG>& tw) {
-  constexpr int L8 = Plan<LG>::L8, R = Plan<LG>::RM, MI = Plan<LG>::MI, TPS = Plan<LG>::TPS;
+  constexpr int L8 = Plan<LG>::L8, R = Plan<LG>::RM, TPS = LAY::TPS;
+  constexpr int MI = TPS < 64 ? (64 + TPS - 1) / TPS : 1;
   static_assert(MI * R <= 12, "middle-stage items of a lane must fit x[]");
-  const bool a8 = u < L8, am = u < 64;
+  static_assert(TPS >= 64 || TPS % 8 == 0, "items of one lane must share their middle-stage twiddles");
+  const bool a8 = u < L8;
   if (a8) dft8<SIGN>(v);
   Cx<T>* w = sel.next();
   if (a8) {
@@ -529,21 +537,23 @@ __device__ __forceinline__ void fft_run_mixed(Cx<T> (&v)[8], TileSel<T, PP>& sel
   }
   __syncthreads();
   Cx<T> x[12];
-  if (am) {
-    const Cx<T>* r = sel.cur;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    if (u + i * TPS < 64) {
+      const Cx<T>* r = sel.cur;
 #pragma unroll
       for (int q = 0; q < R; ++q) x[i * R + q] = r[LAY::idx(u + i * TPS + 64 * q, t)];
+    }
   }
   sel.after_read();
   w = sel.next();
-  if (am) {
+  {
     // table values rather than running powers: eleven chained products would cost accuracy
     // (items u and u + TPS share u mod 8, hence their twiddles)
     const int k = u & 7;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (u + i * TPS >= 64) continue;
       Cx<T> y[12];
       y[0] = x[i * R];
 #pragma unroll
@@ -654,10 +664,14 @@ __device__ __forceinline__ size_t rowB(const PGeo& G, int c, int z, int kyp) {
          (size_t)G.KXP;
 }
 
-template <typename T, int LG, bool ROWS, int WANT_COLS = 0>
+// DENSE (column kernels of the mixed plans with 32 < L/8 < 64, i.e. 320 and 384 points): L/8 lanes per sequence
+// instead of 64, so no wave idles through the radix-8 stages and the workgroup (16 L/8 lanes: 640 or 768) may hold
+// 168 registers per lane instead of 128.
+template <typename T, int LG, bool ROWS, int WANT_COLS = 0, bool DENSE = false>
 struct TileCfg {
   static constexpr int L = Plan<LG>::L, L8 = Plan<LG>::L8;
-  static constexpr int TPS = Plan<LG>::TPS;
+  static constexpr bool DENSE_ON = DENSE && !ROWS && !Plan<LG>::POW2 && L8 > 32 && L8 < 64;
+  static constexpr int TPS = DENSE_ON ? L8 : Plan<LG>::TPS;
   static constexpr int TS = tile_seqs(L, TPS, sizeof(T) == 4, ROWS, WANT_COLS, Plan<LG>::POW2), NT = TS * TPS;
   static constexpr int PITCH = L + L / 8 + 1;                            // row layout
   // waves per SIMD the register allocation must allow: single precision column kernels of 512
@@ -666,7 +680,7 @@ struct TileCfg {
   static constexpr int ELEMS = ROWS ? TS * PITCH : L * TS;               // one tile
   static constexpr bool PP = 2 * ELEMS * sizeof(Cx<T>) <= kLdsBudget;    // room for two tiles
   static constexpr size_t BYTES = ((PP ? 2 : 1) * ELEMS + TwTab<LG>::SIZE) * sizeof(Cx<T>);  // tiles, twiddle table
-  using Lay = typename std::conditional<ROWS, RowLayout<PITCH>, ColLayout<TS>>::type;
+  using Lay = typename std::conditional<ROWS, RowLayout<PITCH, TPS>, ColLayout<TS, TPS>>::type;
   // column tiles per 128-byte line
   static constexpr int PF = (!ROWS && TS * sizeof(Cx<T>) < 128) ? 128 / (TS * (int)sizeof(Cx<T>)) : 1;
 };
@@ -701,8 +715,15 @@ struct TileCfg {
 
 // Tile shape of the z convolution: that of the y kernels unless SMI_FFT_ZCOLS asks for another
 // width (8-column tiles, i.e. two 512-lane workgroups per CU, measured slower at every length).
+// 1: the z convolution of the 320- and 384-point plans on dense tiles (see TileCfg) in its full form (Green's values
+// of both parities held across tiles, next column requested two transforms ahead: 163 / 152 registers, no scratch);
+// 2: dense tiles, lean form; 0: 64 lanes per sequence, lean form.  Measured z convolution at 384^3: 1.75 / 1.83 / 1.92
+// ms; at 320^3: 1.13 / 1.19 / 1.21 ms.
+#ifndef SMI_FFT_ZDENSE
+#define SMI_FFT_ZDENSE 1
+#endif
 template <typename T, int LG, int WC = SMI_FFT_ZCOLS>
-using ZCfg = TileCfg<T, LG, false, WC>;
+using ZCfg = TileCfg<T, LG, false, WC, SMI_FFT_ZDENSE != 0>;
 
 // ------------------------------------------------------------------------- y forward
 // The y kernels walk over G.zg consecutive planes and the G.nc components of one column tile
@@ -856,7 +877,7 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
   // do not fit 128 registers with the Green's values of both parities held across tiles and the
   // next column requested two transforms ahead: they reload the former per tile and request the
   // latter one transform ahead.
-  constexpr bool LEAN = !Plan<LG>::POW2 && Plan<LG>::RM > SMI_FFT_LEAN_ABOVE;
+  constexpr bool LEAN = !Plan<LG>::POW2 && Plan<LG>::RM > SMI_FFT_LEAN_ABOVE && !(Cfg::DENSE_ON && SMI_FFT_ZDENSE == 1);
   int ct, kyc, k;
   if (!col_tile<Cfg::PF>(G, ct, kyc, k)) return;
   const int col = G.colbase + ct * TS + t;
