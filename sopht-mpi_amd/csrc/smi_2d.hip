@@ -31,13 +31,24 @@
     }                                                                                     \
   } while (0)
 
+// smi_comm.hip: block r of `send` goes to rank r, block s of `recv` comes from rank s
+int smi_alltoall_impl(smi_ctx* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream);
+
 struct smi_poisson2d {
   smi_ctx* ctx;
   int ny, nx;       // the whole plane (ny = rows of all ranks)
   int ny_local;     // rows of this rank, starting at row0 of the plane
   int row0;
-  void* gather_send;  // several ranks: this rank's interior rows, one copy per peer for the host-staged transport
-  void* gather_recv;  // several ranks: the interior of the whole plane, (ny, nx)
+  // Several ranks: the transform is divided, rows <-> spectral columns (smi2d_poisson_solve).  KL columns of the
+  // nx + 1 (padded to KL * nranks) per rank; row_fwd / row_inv: batched 1D transforms of this rank's rows (2nx
+  // points); col: batched strided 1D transform of its columns (2ny points), both directions.
+  int KL;
+  hipfftHandle row_fwd, row_inv, col;
+  void* row_real;   // (ny_local, 2nx) reals
+  void* row_spec;   // (ny_local, nx + 1) complex
+  void* xchg;       // (nranks, ny_local, KL) complex: blocks by peer
+  void* col_spec;   // (2ny, KL) complex
+  void* ghat_cols;  // (2ny, KL) complex: this rank's columns of ghat
   hipfftHandle fwd, inv;
   // The captured step of smi2d_flow_step_ns (single rank): executable graph, what it was captured for, and the
   // device array its kernels read the per-step coefficients from
@@ -278,6 +289,53 @@ __global__ void __launch_bounds__(kB) k2_extract(T* __restrict__ sol, const T* _
   const int y = (int)(i / nx), x = (int)(i - (long long)y * nx);
   sol[(long long)(y + g) * px + x + g] = dbl[(long long)(y + row0) * 2 * nx + x];
 }
+// ---- divided transform (several ranks)
+// this rank's interior rows, zero padded to 2nx
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_pad_rows(T* __restrict__ rows, const T* __restrict__ rhs, int ny, int nx,
+                                                 int g, int px) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2LL * ny * nx) return;
+  const int y = (int)(i / (2 * nx)), x = (int)(i - (long long)y * 2 * nx);
+  rows[i] = x < nx ? rhs[(long long)(y + g) * px + x + g] : T(0);
+}
+// row spectra (ny, nx + 1) <-> blocks by peer (P, ny, KL): peer r holds columns r KL .. r KL + KL - 1 (zeros past nx)
+template <typename T, bool TO_BLOCKS>
+__global__ void __launch_bounds__(kB) k2_col_blocks(T* __restrict__ spec, T* __restrict__ blocks, int ny, int nx,
+                                                   int KL, int P) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)P * ny * KL) return;
+  const int k = (int)(i % KL);
+  const long long t = i / KL;
+  const int y = (int)(t % ny), r = (int)(t / ny);
+  const int col = r * KL + k;
+  if (TO_BLOCKS) {
+    const bool in = col <= nx;
+    const long long src = (long long)y * (nx + 1) + col;
+    blocks[2 * i] = in ? spec[2 * src] : T(0);
+    blocks[2 * i + 1] = in ? spec[2 * src + 1] : T(0);
+  } else if (col <= nx) {
+    const long long dst = (long long)y * (nx + 1) + col;
+    spec[2 * dst] = blocks[2 * i];
+    spec[2 * dst + 1] = blocks[2 * i + 1];
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_fill_zero(T* __restrict__ a, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = T(0);
+}
+// columns c0 .. c0 + KL - 1 of the (rows, nx + 1) spectrum -> (rows, KL), zeros past nx
+template <typename T>
+__global__ void __launch_bounds__(kB) k2_take_cols(T* __restrict__ out, const T* __restrict__ full, int rows, int nx,
+                                                  int KL, int c0) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * KL) return;
+  const int k = (int)(i % KL), y = (int)(i / KL), col = c0 + k;
+  const long long src = (long long)y * (nx + 1) + col;
+  out[2 * i] = col <= nx ? full[2 * src] : T(0);
+  out[2 * i + 1] = col <= nx ? full[2 * src + 1] : T(0);
+}
 // interior of a ghosted array -> dense (ny, nx)
 template <typename T>
 __global__ void __launch_bounds__(kB) k2_pack_interior(T* __restrict__ dense, const T* __restrict__ f, int ny, int nx,
@@ -382,19 +440,6 @@ int ghost_sum2(smi_ctx* c, void* field, int ncomp) {
 
 // Every rank's block of `bytes` bytes -> all blocks in rank order on every rank.  `send` holds room for one copy of
 // the block per rank: the host-staged transport only knows an all-to-all, which gets the block replicated.
-int allgather2(smi_ctx* c, void* send, void* recv, size_t bytes) {
-  if (c->alltoall_cb) {
-    for (int r = 1; r < c->nranks; ++r)
-      SMI_CHECK_HIP(hipMemcpyAsync((char*)send + r * bytes, send, bytes, hipMemcpyDeviceToDevice, c->stream));
-    int rc = c->alltoall_cb(c->exchange_user, send, recv, bytes);
-    SMI_REQUIRE(rc == 0, "2D all-gather callback failed (%d)", rc);
-    return 0;
-  }
-  SMI_REQUIRE(c->comm_ready, "2D Poisson solve across ranks needs smi_comm_init or a transport callback");
-  SMI_CHECK_NCCL(ncclAllGather(send, recv, bytes, ncclChar, c->comm, c->stream));
-  return 0;
-}
-
 template <typename T>
 int fft_forward(smi_poisson2d* p, void* real_in, void* cplx_out) {
   if (sizeof(T) == 4)
@@ -572,18 +617,13 @@ extern "C" int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* c, const void*
   const size_t es = smi_elem_size(c);
   const size_t nreal = 4 * (size_t)p->ny * p->nx, ncplx = 2 * (size_t)p->ny * (p->nx + 1);
   const bool f32 = c->dtype == SMI_F32;
+  const int P = c->nranks;
   SMI_CHECK_HIP(hipSetDevice(c->device));
   SMI_CHECK_HIP(hipMalloc(&p->real_buf, nreal * es));
   SMI_CHECK_HIP(hipMalloc(&p->cplx_buf, ncplx * 2 * es));
   SMI_CHECK_HIP(hipMalloc(&p->ghat, ncplx * 2 * es));
-  if (c->nranks > 1) {
-    SMI_CHECK_HIP(hipMalloc(&p->gather_send, (size_t)p->ny * p->nx * es));
-    SMI_CHECK_HIP(hipMalloc(&p->gather_recv, (size_t)p->ny * p->nx * es));
-  }
   SMI_CHECK_FFT2(hipfftPlan2d(&p->fwd, 2 * p->ny, 2 * p->nx, f32 ? HIPFFT_R2C : HIPFFT_D2Z));
-  SMI_CHECK_FFT2(hipfftPlan2d(&p->inv, 2 * p->ny, 2 * p->nx, f32 ? HIPFFT_C2R : HIPFFT_Z2D));
   SMI_CHECK_FFT2(hipfftSetStream(p->fwd, c->stream));
-  SMI_CHECK_FFT2(hipfftSetStream(p->inv, c->stream));
   SMI_CHECK_HIP(hipMemcpyAsync(p->real_buf, greens_host, nreal * es, hipMemcpyHostToDevice, c->stream));
   // dx^2 of the reference and the 1 / (2ny 2nx) of its normalised backward transform, folded in
   const double scale = dx * dx / (4.0 * (double)p->ny * (double)p->nx);
@@ -592,6 +632,42 @@ extern "C" int smi2d_poisson_create(smi_poisson2d** out, smi_ctx* c, const void*
     k2_scale<T><<<nblocks(2 * (long long)ncplx), kB, 0, c->stream>>>((T*)p->ghat, (T)scale, 2 * (long long)ncplx);
   });
   SMI_LAUNCH_CHECK();
+  if (P == 1) {
+    SMI_CHECK_FFT2(hipfftPlan2d(&p->inv, 2 * p->ny, 2 * p->nx, f32 ? HIPFFT_C2R : HIPFFT_Z2D));
+    SMI_CHECK_FFT2(hipfftSetStream(p->inv, c->stream));
+  } else {
+    // Divided transform: keep this rank's columns of the Green's spectrum, drop the whole-plane buffers and plan
+    // (they served the set-up only), and plan the batched row and column transforms.
+    p->KL = (p->nx + 1 + P - 1) / P;
+    const size_t ncols = 2 * (size_t)p->ny * p->KL;
+    SMI_CHECK_HIP(hipMalloc(&p->ghat_cols, ncols * 2 * es));
+    SMI_DISPATCH(c, {
+      k2_take_cols<T><<<nblocks((long long)ncols), kB, 0, c->stream>>>((T*)p->ghat_cols, (const T*)p->ghat, 2 * p->ny,
+                                                                      p->nx, p->KL, c->rank * p->KL);
+    });
+    SMI_LAUNCH_CHECK();
+    SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+    hipfftDestroy(p->fwd);
+    p->fwd = 0;
+    SMI_CHECK_HIP(hipFree(p->real_buf));
+    SMI_CHECK_HIP(hipFree(p->cplx_buf));
+    SMI_CHECK_HIP(hipFree(p->ghat));
+    p->real_buf = p->cplx_buf = p->ghat = nullptr;
+    SMI_CHECK_HIP(hipMalloc(&p->row_real, 2 * (size_t)p->ny_local * p->nx * es));
+    SMI_CHECK_HIP(hipMalloc(&p->row_spec, (size_t)p->ny_local * (p->nx + 1) * 2 * es));
+    SMI_CHECK_HIP(hipMalloc(&p->xchg, (size_t)P * p->ny_local * p->KL * 2 * es));
+    SMI_CHECK_HIP(hipMalloc(&p->col_spec, ncols * 2 * es));
+    int nrow[1] = {2 * p->nx}, ncol[1] = {2 * p->ny};
+    SMI_CHECK_FFT2(hipfftPlanMany(&p->row_fwd, 1, nrow, nullptr, 1, 0, nullptr, 1, 0, f32 ? HIPFFT_R2C : HIPFFT_D2Z,
+                                  p->ny_local));
+    SMI_CHECK_FFT2(hipfftPlanMany(&p->row_inv, 1, nrow, nullptr, 1, 0, nullptr, 1, 0, f32 ? HIPFFT_C2R : HIPFFT_Z2D,
+                                  p->ny_local));
+    SMI_CHECK_FFT2(hipfftPlanMany(&p->col, 1, ncol, ncol, p->KL, 1, ncol, p->KL, 1, f32 ? HIPFFT_C2C : HIPFFT_Z2Z,
+                                  p->KL));
+    SMI_CHECK_FFT2(hipfftSetStream(p->row_fwd, c->stream));
+    SMI_CHECK_FFT2(hipfftSetStream(p->row_inv, c->stream));
+    SMI_CHECK_FFT2(hipfftSetStream(p->col, c->stream));
+  }
   SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
   *out = p;
   return 0;
@@ -605,8 +681,14 @@ extern "C" int smi2d_poisson_destroy(smi_poisson2d* p) {
   hipFree(p->real_buf);
   hipFree(p->cplx_buf);
   hipFree(p->ghat);
-  if (p->gather_send) hipFree(p->gather_send);
-  if (p->gather_recv) hipFree(p->gather_recv);
+  if (p->row_fwd) hipfftDestroy(p->row_fwd);
+  if (p->row_inv) hipfftDestroy(p->row_inv);
+  if (p->col) hipfftDestroy(p->col);
+  hipFree(p->row_real);
+  hipFree(p->row_spec);
+  hipFree(p->xchg);
+  hipFree(p->col_spec);
+  hipFree(p->ghat_cols);
   if (p->step_exec) hipGraphExecDestroy(p->step_exec);
   if (p->step_graph) hipGraphDestroy(p->step_graph);
   if (p->step_coef) hipFree(p->step_coef);
@@ -614,22 +696,67 @@ extern "C" int smi2d_poisson_destroy(smi_poisson2d* p) {
   return 0;
 }
 
+// Several ranks (slabs of rows): the transform is divided instead of gathered.  Every rank transforms its own rows
+// (zero padded in x only: the zero rows of the doubled plane are never formed), an all-to-all turns rows into
+// spectral columns (KL of the nx + 1 per rank, all ny rows of the plane), the columns are zero padded to 2ny,
+// transformed, multiplied by this rank's columns of the Green's spectrum and transformed back, and the mirror image
+// brings the first ny rows home.  This replaces the reference's MPIDomainDoublingCommunicator2D + PFFT pair
+// (UnboundedPoissonSolverMPI2D.py:120-153, 156-352) with two all-to-alls of (ny / P) x (nx + 1) complex values.
+template <typename T>
+static int solve_divided(smi_poisson2d* p, void* solution, const void* rhs) {
+  smi_ctx* c = p->ctx;
+  const int P = c->nranks, nyl = p->ny_local, nx = p->nx, KL = p->KL;
+  const long long nblk = (long long)P * nyl * KL, nrows = 2LL * nyl * nx;
+  const size_t per_peer = (size_t)nyl * KL * 2 * sizeof(T);
+  constexpr bool f32 = sizeof(T) == 4;
+  k2_pad_rows<T><<<nblocks(nrows), kB, 0, c->stream>>>((T*)p->row_real, (const T*)rhs, nyl, nx, c->g, c->px);
+  if (f32)
+    SMI_CHECK_FFT2(hipfftExecR2C(p->row_fwd, (hipfftReal*)p->row_real, (hipfftComplex*)p->row_spec));
+  else
+    SMI_CHECK_FFT2(hipfftExecD2Z(p->row_fwd, (hipfftDoubleReal*)p->row_real, (hipfftDoubleComplex*)p->row_spec));
+  k2_col_blocks<T, true><<<nblocks(nblk), kB, 0, c->stream>>>((T*)p->row_spec, (T*)p->xchg, nyl, nx, KL, P);
+  SMI_LAUNCH_CHECK();
+  // block s of the result = rows s nyl .. of the plane: the first ny rows of the column array, in order
+  SMI_CHECK(smi_alltoall_impl(c, p->xchg, p->col_spec, per_peer, c->stream));
+  T* pad = (T*)p->col_spec + 2 * (size_t)p->ny * KL;
+  k2_fill_zero<T><<<nblocks(2LL * p->ny * KL), kB, 0, c->stream>>>(pad, 2LL * p->ny * KL);
+  if (f32) {
+    SMI_CHECK_FFT2(hipfftExecC2C(p->col, (hipfftComplex*)p->col_spec, (hipfftComplex*)p->col_spec, HIPFFT_FORWARD));
+  } else {
+    SMI_CHECK_FFT2(hipfftExecZ2Z(p->col, (hipfftDoubleComplex*)p->col_spec, (hipfftDoubleComplex*)p->col_spec,
+                                 HIPFFT_FORWARD));
+  }
+  k2_cmul<T><<<nblocks(2LL * p->ny * KL), kB, 0, c->stream>>>((T*)p->col_spec, (const T*)p->ghat_cols, 2LL * p->ny * KL);
+  if (f32) {
+    SMI_CHECK_FFT2(hipfftExecC2C(p->col, (hipfftComplex*)p->col_spec, (hipfftComplex*)p->col_spec, HIPFFT_BACKWARD));
+  } else {
+    SMI_CHECK_FFT2(hipfftExecZ2Z(p->col, (hipfftDoubleComplex*)p->col_spec, (hipfftDoubleComplex*)p->col_spec,
+                                 HIPFFT_BACKWARD));
+  }
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK(smi_alltoall_impl(c, p->col_spec, p->xchg, per_peer, c->stream));
+  k2_col_blocks<T, false><<<nblocks(nblk), kB, 0, c->stream>>>((T*)p->row_spec, (T*)p->xchg, nyl, nx, KL, P);
+  if (f32)
+    SMI_CHECK_FFT2(hipfftExecC2R(p->row_inv, (hipfftComplex*)p->row_spec, (hipfftReal*)p->row_real));
+  else
+    SMI_CHECK_FFT2(hipfftExecZ2D(p->row_inv, (hipfftDoubleComplex*)p->row_spec, (hipfftDoubleReal*)p->row_real));
+  k2_extract<T><<<nblocks((long long)nyl * nx), kB, 0, c->stream>>>((T*)solution, (const T*)p->row_real, nyl, nx, c->g,
+                                                                   c->px, 0);
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int smi2d_poisson_solve(smi_poisson2d* p, void* solution, const void* rhs) {
   SMI_REQUIRE(p && solution && rhs, "smi2d_poisson_solve: bad argument");
   smi_ctx* c = p->ctx;
+  if (c->nranks > 1) {
+    SMI_DISPATCH(c, { SMI_CHECK(solve_divided<T>(p, solution, rhs)); });
+    return 0;
+  }
   const long long nreal = 4LL * p->ny * p->nx, ncplx = 2LL * p->ny * (p->nx + 1);
   const long long nlocal = (long long)p->ny_local * p->nx;
   SMI_DISPATCH(c, {
-    if (c->nranks > 1) {
-      // the whole right-hand side on every rank, then the single-rank solve of the plane
-      k2_pack_interior<T><<<nblocks(nlocal), kB, 0, c->stream>>>((T*)p->gather_send, (const T*)rhs, p->ny_local, p->nx,
-                                                                 c->g, c->px);
-      SMI_CHECK(allgather2(c, p->gather_send, p->gather_recv, (size_t)nlocal * sizeof(T)));
-      k2_pad_load<T><<<nblocks(nreal), kB, 0, c->stream>>>((T*)p->real_buf, (const T*)p->gather_recv, p->ny, p->nx, 0,
-                                                           p->nx);
-    } else {
-      k2_pad_load<T><<<nblocks(nreal), kB, 0, c->stream>>>((T*)p->real_buf, (const T*)rhs, p->ny, p->nx, c->g, c->px);
-    }
+    k2_pad_load<T><<<nblocks(nreal), kB, 0, c->stream>>>((T*)p->real_buf, (const T*)rhs, p->ny, p->nx, c->g, c->px);
     SMI_CHECK((fft_forward<T>(p, p->real_buf, p->cplx_buf)));
     k2_cmul<T><<<nblocks(ncplx), kB, 0, c->stream>>>((T*)p->cplx_buf, (const T*)p->ghat, ncplx);
     if (sizeof(T) == 4)

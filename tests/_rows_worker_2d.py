@@ -1,7 +1,7 @@
 """Worker of the multi-rank 2D GPU test: P ranks share the one GPU of the test box, each owns a slab of rows of the
 plane (the reference's default 2D decomposition), transport is host-staged through the socket world.  Rank 0 gathers
 the slabs and compares with the single-rank oracle on the whole plane: ghost-row exchange of every stencil operator,
-the gathered Poisson solve, node ownership, the ghost sum of the spread, the reductions."""
+the divided Poisson solve (rows, all-to-all, spectral columns), node ownership, the ghost sum of the spread, the reductions."""
 import os
 import sys
 

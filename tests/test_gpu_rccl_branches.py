@@ -1,5 +1,5 @@
 """GPU, several ranks on one GPU: the library's RCCL branches (ncclSend / ncclRecv halo and ghost-sum groups, the
-grouped all-to-all of the FFT transposes on the communication stream, the pencil redistribution, the 2D all-gather,
+grouped all-to-all of the FFT transposes on the communication stream, the pencil redistribution, the transposes of the divided 2D solve,
 the all-reduce) against the single-rank oracle.
 
 RCCL refuses two ranks on one device, so these branches cannot run over RCCL itself on a one-GPU box.  Here the
