@@ -159,6 +159,48 @@ def test_benchmark_workload_over_slabs_equals_the_single_rank_run(tmp_path, n, n
         assert np.abs(whole[k] - parts[k]).max() <= 2e-5 * scale, (k, np.abs(whole[k] - parts[k]).max(), scale)
 
 
+@pytest.mark.parametrize("n,nranks", [(256, 4), (256, 8)])
+def test_benchmark_workload_over_pencils_equals_the_single_rank_run(tmp_path, n, nranks):
+    """The benchmark workload on the reference's default decomposition (2 x 2 and 4 x 2 pencils over z and y) through
+    the one-call step - one-pass advection + diffusion across the inner y faces, Poisson solve routed through the
+    slab decomposition - over the RCCL branches, against the single-rank run: diagnostics, plane sums, and element by
+    element the planes next to every z boundary and one mid-block plane (whole planes, so the rows on either side
+    of every y boundary are among them)."""
+    import json
+
+    import numpy as np
+
+    from helpers import assert_close
+
+    if not os.path.exists(STANDIN):
+        pytest.skip("tests/rccl_standin/libsophtmi_standin.so is not built (make standin)")
+    out_dir = str(tmp_path)
+    pz, py = {4: (2, 2), 8: (4, 2)}[nranks]
+    nzl = n // pz
+    dump = sorted({b + d for b in range(nzl, n, nzl) for d in (-2, -1, 0, 1)} | {nzl // 2})
+    _single_and_slabs("_full_size_ranks_worker.py", n, 2, nranks, 29940 + nranks, out_dir, None,
+                      [",".join(map(str, dump)), "pencil"])
+    for z in dump:
+        one = np.load(os.path.join(out_dir, f"plane_1_{z}.npy"))
+        many = np.concatenate([np.load(os.path.join(out_dir, f"plane_{nranks}_{z}_y{ry}.npy")) for ry in range(py)],
+                              axis=1)
+        for k, name in enumerate(("wx", "wy", "wz", "ux", "uy", "uz")):
+            assert_close(many[k], one[k], np.float32, factor=1.0, what=f"{name} of plane {z}, {nranks} pencils vs one")
+    a = json.load(open(os.path.join(out_dir, "diag_1.json")))
+    b = json.load(open(os.path.join(out_dir, f"diag_{nranks}.json")))
+    assert abs(a["dt"] - b["dt"]) <= 1e-6 * a["dt"] and abs(a["dt_after"] - b["dt_after"]) <= 1e-5 * a["dt_after"]
+    assert abs(a["max_vorticity"] - b["max_vorticity"]) <= 1e-5 * a["max_vorticity"]
+    assert abs(a["divergence_l2"] - b["divergence_l2"]) <= 1e-3 * a["divergence_l2"] + 1e-7
+    whole = np.load(os.path.join(out_dir, "planes_1_0.npy"))
+    parts = np.zeros_like(whole)
+    for r in range(nranks):
+        cz = int(np.load(os.path.join(out_dir, f"block_{nranks}_{r}.npy"))[0])
+        parts[:, cz * nzl:(cz + 1) * nzl] += np.load(os.path.join(out_dir, f"planes_{nranks}_{r}.npy"))
+    for k in range(6):
+        scale = np.abs(whole[k]).max()
+        assert np.abs(whole[k] - parts[k]).max() <= 2e-5 * scale, (k, np.abs(whole[k] - parts[k]).max(), scale)
+
+
 def test_rod_configuration_over_four_slabs_equals_the_single_rank_run(tmp_path):
     """The shape of the reference's flow-past-rod configuration (384^3, filter of order 1, 5 760 surface nodes on an
     inclined rod) on 4 slabs over the RCCL branches against the single-rank run: the slabs take the host path of the
