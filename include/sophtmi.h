@@ -116,6 +116,23 @@ int smi_set_group_alltoall_callback(smi_ctx* ctx, smi_group_alltoall_cb cb);
 typedef int (*smi_p2p_cb)(void* user, int nsend, const int* send_peers, const void* const* sends, int nrecv,
                           const int* recv_peers, void* const* recvs, size_t bytes);
 int smi_set_p2p_callback(smi_ctx* ctx, smi_p2p_cb cb);
+/* ---- general block topology: the ghost exchange on any decomposition, periodic or not ---------------
+ * MPIConstruct3D / 2D accept any rank_distribution and periodic_domain (utils/mpi_utils_3d.py:7-83,
+ * utils/mpi_utils_2d.py:9-84), and the reference's own tests of MPIGhostCommunicator3D / 2D
+ * (utils/mpi_utils_3d.py:86-1142, utils/mpi_utils_2d.py:87-421) run on periodic domains with x divided.
+ * smi_ctx_set_block turns a context created as rank `(cz * Py + cy) * Px + cx` (the Cartesian order of Create_cart)
+ * into block (cz, cy, cx) of a (Pz, Py, Px) grid with the given periodic axes; smi_halo_exchange_general then fills
+ * the ghost cells of `field` from the neighbouring blocks (faces; with full_exchange also edges and vertices; a
+ * periodic axis with one rank wraps onto the block itself).  Messages travel through smi_set_p2p_callback or RCCL.
+ * The operators of this library keep x whole and the domain unbounded: on such a context they fail with an
+ * error, only the exchange is served. */
+int smi_ctx_set_block(smi_ctx* ctx, const int* coords_zyx, const int* topo_zyx, const int* periodic_zyx);
+/* smi_ctx_create + smi_ctx_set_block for blocks as thin as their ghost layers (smi_ctx_create asks for two interior
+ * layers per ghost layer, which the operators need; the reference's communicator tests run 8-point axes over 4 ranks
+ * with 2 ghost layers). */
+int smi_ctx_create_block(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost, int rank, int nranks,
+                         const int* coords_zyx, const int* topo_zyx, const int* periodic_zyx);
+int smi_halo_exchange_general(smi_ctx* ctx, void* field, int ncomp, int full_exchange);
 /* MPIDomainDoublingCommunicator-style redistribution between the two decompositions of one grid:
  * `pencil_field` (ncomp components, ghosted, on `pencil`) <-> `slab_field` (ghosted, on `slab`, a context of
  * the same rank and rank count created with nz = global nz / nranks, ny = global ny).  Interiors only.

@@ -142,6 +142,9 @@ int smi_halo_exchange2_impl(smi_ctx* c, void* field_a, int ncomp_a, void* field_
 }
 
 int smi_halo_exchange2_on(smi_ctx* c, void* field_a, int ncomp_a, void* field_b, int ncomp_b, hipStream_t stream) {
+  SMI_REQUIRE(!c->blk_on,
+              "this operator needs slabs or pencils over z and y of an unbounded domain; a context with a general "
+              "block topology (smi_ctx_set_block) serves smi_halo_exchange_general only");
   if (c->nranks == 1) return 0;
   const int d = (c->halo_depth > 0 && c->halo_depth < c->g) ? c->halo_depth : c->g;
   void* fields[2] = {field_a, field_b};
@@ -251,6 +254,151 @@ int smi_alltoall_slice_impl(smi_ctx* c, const void* send, void* recv, size_t pee
 extern "C" int smi_set_alltoall_callback(smi_ctx* c, smi_alltoall_cb cb) {
   SMI_REQUIRE(c, "smi_set_alltoall_callback: null context");
   c->alltoall_cb = cb;
+  return 0;
+}
+
+// ---------------------------------------------------------------- general block topology
+// MPIConstruct3D / 2D with any rank_distribution and periodic_domain (utils/mpi_utils_3d.py:7-83, mpi_utils_2d.py:9-84)
+// and the ghost exchange of MPIGhostCommunicator3D / 2D on it (utils/mpi_utils_3d.py:86-1142: faces, and with
+// full_exchange edges and vertices).  The operators of this library keep x whole and the domain unbounded; a
+// context turned into a general block serves the exchange only.
+extern "C" int smi_ctx_set_block(smi_ctx* c, const int* coords_zyx, const int* topo_zyx, const int* periodic_zyx) {
+  SMI_REQUIRE(c && coords_zyx && topo_zyx && periodic_zyx, "smi_ctx_set_block: null argument");
+  long long n = 1, r = 0;
+  for (int a = 0; a < 3; ++a) {
+    SMI_REQUIRE(topo_zyx[a] >= 1 && coords_zyx[a] >= 0 && coords_zyx[a] < topo_zyx[a],
+                "smi_ctx_set_block: position %d of %d along axis %d", coords_zyx[a], topo_zyx[a], a);
+    n *= topo_zyx[a];
+    r = r * topo_zyx[a] + coords_zyx[a];
+  }
+  SMI_REQUIRE(n == c->nranks && r == c->rank, "smi_ctx_set_block: block (%d, %d, %d) of a %d x %d x %d grid is not rank %d of %d",
+              coords_zyx[0], coords_zyx[1], coords_zyx[2], topo_zyx[0], topo_zyx[1], topo_zyx[2], c->rank, c->nranks);
+  SMI_REQUIRE(c->nz > 1 || topo_zyx[0] == 1, "smi_ctx_set_block: a 2D context (nz = 1) has no ranks along z");
+  for (int a = 0; a < 3; ++a) {
+    c->blk_coords[a] = coords_zyx[a];
+    c->blk_topo[a] = topo_zyx[a];
+    c->blk_periodic[a] = periodic_zyx[a] != 0;
+  }
+  c->blk_on = 1;
+  return 0;
+}
+
+namespace {
+// a box of `field` (or of a packed buffer) to a box of the same extents elsewhere: strides in elements
+struct BoxSide {
+  long long comp, z, y, off;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) k_box_copy(T* __restrict__ dst, const T* __restrict__ src, int bz, int by, int bx,
+                                                 BoxSide D, BoxSide S, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % bx);
+  long long r = i / bx;
+  const int y = (int)(r % by);
+  r /= by;
+  const int z = (int)(r % bz), k = (int)(r / bz);
+  dst[D.off + k * D.comp + z * D.z + y * D.y + x] = src[S.off + k * S.comp + z * S.z + y * S.y + x];
+}
+}  // namespace
+
+// Ghost cells of `field` from the neighbouring blocks, axis by axis (z, y, x).  full_exchange: the faces of an axis
+// span the whole padded extent of the axes already done, fresh ghost cells included, so edges and vertices arrive
+// without diagonal messages; otherwise faces span interiors only.  A periodic axis with a single rank wraps onto
+// the block itself.
+extern "C" int smi_halo_exchange_general(smi_ctx* c, void* field, int ncomp, int full_exchange) {
+  SMI_REQUIRE(c && field && ncomp >= 1 && ncomp <= 3, "smi_halo_exchange_general: bad argument");
+  SMI_REQUIRE(c->blk_on, "smi_halo_exchange_general: the context has no block topology (smi_ctx_set_block)");
+  const bool two_d = c->nz == 1;
+  const int g = c->g;
+  const int p[3] = {two_d ? 1 : c->pz, c->py, c->px};
+  const int gh[3] = {two_d ? 0 : g, g, g};
+  const long long comp_stride = two_d ? (long long)c->plane : (long long)c->vol;
+  const BoxSide F{comp_stride, (long long)c->plane, (long long)c->px, 0};
+  const size_t es = smi_elem_size(c);
+  auto rank_of = [&](int a, int shift) {
+    int co[3] = {c->blk_coords[0], c->blk_coords[1], c->blk_coords[2]};
+    co[a] = (co[a] + shift + c->blk_topo[a]) % c->blk_topo[a];
+    return (co[0] * c->blk_topo[1] + co[1]) * c->blk_topo[2] + co[2];
+  };
+  for (int a = two_d ? 1 : 0; a < 3; ++a) {
+    const int P = c->blk_topo[a], co = c->blk_coords[a];
+    const bool per = c->blk_periodic[a];
+    const bool lo = co > 0 || per, hi = co < P - 1 || per;
+    if (!lo && !hi) continue;
+    // extents of the box on every axis: g layers along a, interiors or whole padded extents on the others
+    int b0[3], bn[3];
+    for (int b = 0; b < 3; ++b) {
+      const bool whole = full_exchange && b < a;
+      b0[b] = whole ? 0 : gh[b];
+      bn[b] = whole ? p[b] : p[b] - 2 * gh[b];
+    }
+    bn[a] = g;
+    const long long n = (long long)ncomp * bn[0] * bn[1] * bn[2];
+    const size_t bytes = (size_t)n * es;
+    const BoxSide B{(long long)bn[0] * bn[1] * bn[2], (long long)bn[1] * bn[2], (long long)bn[2], 0};
+    auto at = [&](int start_a) {  // the box whose first layer along a is start_a
+      int o[3] = {b0[0], b0[1], b0[2]};
+      o[a] = start_a;
+      BoxSide s = F;
+      s.off = (long long)o[0] * (long long)c->plane + (long long)o[1] * c->px + o[2];
+      return s;
+    };
+    const BoxSide edge_lo = at(g), edge_hi = at(p[a] - 2 * g), ghost_lo = at(0), ghost_hi = at(p[a] - g);
+    const int blocks = (int)((n + 255) / 256);
+    auto copy = [&](void* dst, BoxSide D, const void* src, BoxSide S) {
+      SMI_DISPATCH(c, {
+        k_box_copy<T><<<blocks, 256, 0, c->stream>>>((T*)dst, (const T*)src, bn[0], bn[1], bn[2], D, S, n);
+      });
+      return 0;
+    };
+    if (P == 1) {  // periodic onto itself
+      copy(field, ghost_lo, field, edge_hi);
+      copy(field, ghost_hi, field, edge_lo);
+      SMI_LAUNCH_CHECK();
+      continue;
+    }
+    if (c->blk_cap < bytes) {
+      SMI_CHECK_HIP(hipSetDevice(c->device));
+      SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+      for (void*& b : c->blk_buf) {
+        if (b) SMI_CHECK_HIP(hipFree(b));
+        b = nullptr;
+      }
+      c->blk_cap = 0;
+      for (void*& b : c->blk_buf) SMI_CHECK_HIP(hipMalloc(&b, bytes));
+      c->blk_cap = bytes;
+    }
+    if (lo) copy(c->blk_buf[0], B, field, edge_lo);
+    if (hi) copy(c->blk_buf[1], B, field, edge_hi);
+    SMI_LAUNCH_CHECK();
+    const int peer_lo = rank_of(a, -1), peer_hi = rank_of(a, +1);
+    if (lo && hi && peer_lo == peer_hi) {
+      // two ranks on a periodic axis: both faces go to the same peer, one message per call keeps them apart
+      const void* s1[1] = {c->blk_buf[0]};
+      void* r1[1] = {c->blk_buf[3]};  // the peer's low edge is this block's high ghost
+      SMI_CHECK(smi_p2p_exchange(c, 1, &peer_lo, s1, 1, &peer_hi, r1, bytes));
+      const void* s2[1] = {c->blk_buf[1]};
+      void* r2[1] = {c->blk_buf[2]};
+      SMI_CHECK(smi_p2p_exchange(c, 1, &peer_hi, s2, 1, &peer_lo, r2, bytes));
+    } else {
+      int sp[2], rp[2], ns = 0, nr = 0;
+      const void* sb[2];
+      void* rb[2];
+      if (lo) {
+        sp[ns] = peer_lo, sb[ns++] = c->blk_buf[0];
+        rp[nr] = peer_lo, rb[nr++] = c->blk_buf[2];
+      }
+      if (hi) {
+        sp[ns] = peer_hi, sb[ns++] = c->blk_buf[1];
+        rp[nr] = peer_hi, rb[nr++] = c->blk_buf[3];
+      }
+      SMI_CHECK(smi_p2p_exchange(c, ns, sp, sb, nr, rp, rb, bytes));
+    }
+    if (lo) copy(field, ghost_lo, c->blk_buf[2], B);
+    if (hi) copy(field, ghost_hi, c->blk_buf[3], B);
+    SMI_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -34,6 +34,12 @@ struct smi_ctx {
   smi_sendrecv_cb sendrecv_cb;
   smi_group_alltoall_cb group_alltoall_cb;
   smi_p2p_cb p2p_cb;
+  // General block topology (smi_ctx_set_block): the ranks form a (Pz, Py, Px) grid in Cartesian order, any axis may
+  // be divided and any axis periodic.  Only the ghost exchange (smi_halo_exchange_general) serves such a context.
+  int blk_on;
+  int blk_coords[3], blk_topo[3], blk_periodic[3];
+  void* blk_buf[4];      // packed faces: to the low / high neighbour, from the low / high neighbour
+  size_t blk_cap;
   void* dbl_stage[3];    // staging blocks of the doubled-domain copies across ranks (smi_fftapi.hip)
   size_t dbl_stage_cap;
   hipStream_t stream;
@@ -152,6 +158,10 @@ int smi_halo_exchange2_impl(smi_ctx* ctx, void* field_a, int ncomp_a, void* fiel
 // the same exchange queued on `stream` (RCCL transport only: the host-staged callback works on the context's stream)
 int smi_halo_exchange2_on(smi_ctx* ctx, void* field_a, int ncomp_a, void* field_b, int ncomp_b, hipStream_t stream);
 int smi_y_face_exchange(smi_ctx* ctx, void* field, int ncomp, int depth, bool sum, hipStream_t stream);
+// A few equal-sized messages between device buffers of the ranks (smi_fftapi.hip): sends[i] goes to rank
+// send_peers[i], recvs[j] comes from rank recv_peers[j]; one RCCL group or the point-to-point callback.
+int smi_p2p_exchange(smi_ctx* c, int nsend, const int* send_peers, const void* const* sends, int nrecv,
+                     const int* recv_peers, void* const* recvs, size_t bytes);
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);

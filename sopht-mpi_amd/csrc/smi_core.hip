@@ -37,8 +37,29 @@ static int ctx_allocate(smi_ctx* c) {
   return 0;
 }
 
+// layers_needed: interior layers per ghost layer a block must have along every axis - 2 for the operators (their
+// bands next to a face and the planes they send must not overlap), 1 for a block that only exchanges ghost cells
+static int ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost, int rank, int nranks,
+                      int layers_needed);
+
 extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost,
                               int rank, int nranks) {
+  return ctx_create(out, device, dtype, nz, ny, nx, ghost, rank, nranks, 2);
+}
+
+extern "C" int smi_ctx_create_block(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost, int rank,
+                                    int nranks, const int* coords_zyx, const int* topo_zyx, const int* periodic_zyx) {
+  SMI_CHECK(ctx_create(out, device, dtype, nz, ny, nx, ghost, rank, nranks, 1));
+  const int rc = smi_ctx_set_block(*out, coords_zyx, topo_zyx, periodic_zyx);
+  if (rc != 0) {
+    smi_ctx_destroy(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+static int ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int nx, int ghost, int rank, int nranks,
+                      int layers_needed) {
   SMI_REQUIRE(out, "smi_ctx_create: null output");
   SMI_REQUIRE(dtype == SMI_F32 || dtype == SMI_F64, "smi_ctx_create: invalid dtype %d", dtype);
   SMI_REQUIRE(nz > 0 && ny > 0 && nx > 0, "smi_ctx_create: invalid grid %d %d %d", nz, ny, nx);
@@ -46,8 +67,9 @@ extern "C" int smi_ctx_create(smi_ctx** out, int device, int dtype, int nz, int 
   SMI_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "smi_ctx_create: invalid rank %d of %d", rank,
               nranks);
   // nz == 1 is the plane of the 2D operators, which ignore the z extent (several ranks: slabs of rows)
-  SMI_REQUIRE((nz == 1 || nz >= 2 * ghost) && ny >= 2 * ghost && nx >= 2 * ghost,
-              "smi_ctx_create: local grid %d %d %d smaller than 2*ghost", nz, ny, nx);
+  const int least = layers_needed * ghost;
+  SMI_REQUIRE((nz == 1 || nz >= least) && ny >= least && nx >= least,
+              "smi_ctx_create: local grid %d %d %d smaller than %d*ghost", nz, ny, nx, layers_needed);
   SMI_CHECK_HIP(hipSetDevice(device));
   SMI_CHECK(smi_pruned_scratch_init(device));
   smi_ctx* c = new smi_ctx();
@@ -185,6 +207,8 @@ extern "C" int smi_ctx_destroy(smi_ctx* c) {
     if (c->ybuf[i]) hipFree(c->ybuf[i]);
   }
   for (void* b : c->dbl_stage)
+    if (b) hipFree(b);
+  for (void* b : c->blk_buf)
     if (b) hipFree(b);
   delete c->prof;
   if (c->red_partials) hipFree(c->red_partials);

@@ -248,7 +248,7 @@ extern "C" int smi_set_p2p_callback(smi_ctx* c, smi_p2p_cb cb) {
 // A few messages of `bytes` bytes each between device buffers: sends[i] goes to rank send_peers[i], recvs[j] comes
 // from rank recv_peers[j] (a message to this rank itself is a device copy).  One RCCL group, or the host-staged
 // callback of the tests.
-static int p2p_exchange(smi_ctx* c, int nsend, const int* send_peers, const void* const* sends, int nrecv,
+int smi_p2p_exchange(smi_ctx* c, int nsend, const int* send_peers, const void* const* sends, int nrecv,
                         const int* recv_peers, void* const* recvs, size_t bytes) {
   if (c->p2p_cb) {
     SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -256,7 +256,7 @@ static int p2p_exchange(smi_ctx* c, int nsend, const int* send_peers, const void
     SMI_REQUIRE(rc == 0, "point-to-point callback failed (%d)", rc);
     return 0;
   }
-  SMI_REQUIRE(c->comm_ready, "the doubled-domain copies across ranks need smi_comm_init or a point-to-point callback");
+  SMI_REQUIRE(c->comm_ready, "point-to-point messages across ranks need smi_comm_init or a point-to-point callback");
   for (int i = 0; i < nsend; ++i)
     if (send_peers[i] == c->rank)
       for (int j = 0; j < nrecv; ++j)
@@ -328,7 +328,7 @@ static int doubled_copy_slabs(smi_ctx* c, void* local_field, void* local_doubled
     SMI_LAUNCH_CHECK();
     const void* sends[1] = {c->dbl_stage[0]};
     void* recvs[2] = {c->dbl_stage[1], c->dbl_stage[2]};
-    SMI_CHECK(p2p_exchange(c, 1, &parent, sends, lower ? 2 : 0, kids, recvs, bytes));
+    SMI_CHECK(smi_p2p_exchange(c, 1, &parent, sends, lower ? 2 : 0, kids, recvs, bytes));
     if (lower) {
       doubled_block(0, false);
       doubled_block(1, false);
@@ -342,7 +342,7 @@ static int doubled_copy_slabs(smi_ctx* c, void* local_field, void* local_doubled
     }
     const void* sends[2] = {c->dbl_stage[1], c->dbl_stage[2]};
     void* recvs[1] = {c->dbl_stage[0]};
-    SMI_CHECK(p2p_exchange(c, lower ? 2 : 0, kids, sends, 1, &parent, recvs, bytes));
+    SMI_CHECK(smi_p2p_exchange(c, lower ? 2 : 0, kids, sends, 1, &parent, recvs, bytes));
     field_block(false);
     SMI_LAUNCH_CHECK();
   }

@@ -56,6 +56,9 @@ SIGNATURES = {
     "smi_set_sendrecv_callback": [_p, SENDRECV_CB],
     "smi_set_group_alltoall_callback": [_p, GROUP_ALLTOALL_CB],
     "smi_set_p2p_callback": [_p, P2P_CB],
+    "smi_ctx_set_block": [_p, _p, _p, _p],
+    "smi_ctx_create_block": [_pp, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
+    "smi_halo_exchange_general": [_p, _p, _i, _i],
     "smi_poisson_set_pencil_route": [_p, _p, _p, _p, _p, _p],
     "smi_poisson_pencil_solve": [_p, _p, _p, _i],
     "smi_pencil_to_slab": [_p, _p, _p, _p, _i, _p, _p],

@@ -38,7 +38,7 @@ class DeviceContext:
     geometry + HIP stream + (optionally) RCCL comm."""
 
     def __init__(self, local_grid_size, ghost_size, real_t, rank=0, nranks=1, device=None, world=None,
-                 rank_grid=None):
+                 rank_grid=None, block=None):
         self.real_t = np.dtype(real_t).type
         self.local_grid_size = tuple(int(n) for n in local_grid_size)
         self.ghost_size = int(ghost_size)
@@ -47,9 +47,20 @@ class DeviceContext:
         self.device = local_device() if device is None else device
         nz, ny, nx = self.local_grid_size
         h = C.c_void_p()
-        call("smi_ctx_create", C.byref(h), self.device, _dtype_code(real_t), nz, ny, nx, self.ghost_size,
-             self.rank, self.nranks)
+        if block is None:
+            call("smi_ctx_create", C.byref(h), self.device, _dtype_code(real_t), nz, ny, nx, self.ghost_size,
+                 self.rank, self.nranks)
+        else:
+            coords, topo, periodic = block
+            call("smi_ctx_create_block", C.byref(h), self.device, _dtype_code(real_t), nz, ny, nx, self.ghost_size,
+                 self.rank, self.nranks, (C.c_int * 3)(*(int(v) for v in coords)), (C.c_int * 3)(*(int(v) for v in topo)),
+                 (C.c_int * 3)(*(int(bool(v)) for v in periodic)))
         self.handle = h
+        # block = (coords, topology, periodic flags), each (z, y, x): a general decomposition, on which the library
+        # serves the ghost exchange only (smi_ctx_set_block)
+        self.block = block
+        if block is not None:
+            rank_grid = None
         self.rank_grid = (self.nranks, 1) if rank_grid is None else (int(rank_grid[0]), int(rank_grid[1]))
         self.rank_z, self.rank_y = divmod(self.rank, self.rank_grid[1])
         if self.rank_grid[1] > 1:

@@ -34,8 +34,7 @@ class _Grid:
 
     def __init__(self, construct):
         self._c = construct
-        self.coords = np.array([construct.rank // construct.grid_topology[1],
-                                construct.rank % construct.grid_topology[1], 0])
+        self.coords = np.array(np.unravel_index(construct.rank, tuple(int(t) for t in construct.grid_topology)))
 
     def Get_size(self):
         return self._c.size
@@ -50,7 +49,32 @@ class _Grid:
         return self._c.world.bcast_object(obj, root)
 
     def Get_cart_rank(self, coords):
-        return int(coords[0]) * int(self._c.grid_topology[1]) + int(coords[1])
+        return int(np.ravel_multi_index(tuple(int(v) for v in coords), tuple(int(t) for t in self._c.grid_topology)))
+
+
+def _cartesian_neighbours(rank, topology, periodic):
+    """``Cart_shift(axis, 1)`` for every axis of a row-major rank grid: (previous, next) arrays, PROC_NULL past a
+    non-periodic end (utils/mpi_utils_3d.py:64-76)."""
+    topo = tuple(int(t) for t in topology)
+    coords = np.unravel_index(rank, topo)
+    prev, nxt = [], []
+    for axis, n in enumerate(topo):
+        for shift, out in ((-1, prev), (1, nxt)):
+            c = list(coords)
+            c[axis] += shift
+            if 0 <= c[axis] < n or periodic:
+                c[axis] %= n
+                out.append(int(np.ravel_multi_index(c, topo)))
+            else:
+                out.append(PROC_NULL)
+    return np.array(prev), np.array(nxt)
+
+
+_GENERAL_TOPOLOGY = (
+    "{what}: this decomposition (rank grid {topo}, periodic_domain={periodic}) is served by the topology, ghost, "
+    "field and Lagrangian communicators only; the operators, the Poisson solver and the simulators keep the x axis "
+    "whole and the domain unbounded"
+)
 
 
 def compute_dims(nranks, dims):
@@ -86,51 +110,56 @@ class MPIConstruct3D:
 
     ``rank_distribution`` follows the reference: 0 = distribute, 1 = keep aligned; the ranks are factored over
     the distributed axes as MPI.Compute_dims does.  z-slabs ``(0, 1, 1)``, y-slabs ``(1, 0, 1)`` and pencils over
-    z and y ``(0, 0, 1)`` (the reference's default) are served; x stays whole (the transforms and the 16-byte
-    row accesses of the kernels run along it).  ``None`` picks z-slabs here - fewer, larger messages on the
-    point-to-point links of one node - where the reference picks pencils.  Uneven division raises RuntimeError
-    like the reference (:51-57).
+    z and y ``(0, 0, 1)`` (the reference's default) are served by every operator; x stays whole there (the
+    transforms and the 16-byte row accesses of the kernels run along it).  A divided x axis and ``periodic_domain``
+    are served by the topology itself and by the ghost, field and Lagrangian communicators (what the reference's own
+    tests of these classes use); operators, Poisson solver and simulators raise NotImplementedError on them.
+    ``None`` picks z-slabs here - fewer, larger messages on the point-to-point links of one node - where the
+    reference picks pencils.  Uneven division raises RuntimeError like the reference (:51-57).
     """
 
     def __init__(self, grid_size_z, grid_size_y, grid_size_x, periodic_domain=False, real_t=np.float64,
                  rank_distribution=None, world=None):
         self.grid_dim = 3
         self.real_t = real_t
-        if periodic_domain:
-            raise NotImplementedError("periodic domains are not supported")
-        self.periodic_domain = False
+        self.periodic_domain = bool(periodic_domain)
         self.world = get_world() if world is None else world
         self.size, self.rank = self.world.size, self.world.rank
         if rank_distribution is None:
             rank_distribution = [0, 1, 1] if self.size > 1 else [0, 0, 1]
         self.rank_distribution = list(rank_distribution)
-        if self.size > 1 and self.rank_distribution[2] != 1:
-            raise NotImplementedError(
-                f"rank_distribution {self.rank_distribution}: the x axis is never divided (slabs and pencils over "
-                "z and y are supported)"
-            )
         self.grid_topology = compute_dims(self.size, self.rank_distribution) if self.size > 1 else [1, 1, 1]
+        # a divided x axis or a periodic domain: topology and communicators only (the reference's own tests of those
+        # classes run on such decompositions, tests/test_utils/test_mpi_utils_3d.py:95-125)
+        self.general_topology = self.periodic_domain or self.grid_topology[2] > 1
         self.global_grid_size = np.array((grid_size_z, grid_size_y, grid_size_x))
         if np.any(self.global_grid_size % self.grid_topology):
             logger.error("Cannot divide grid evenly to processors in x, y and/or z directions!")
             raise RuntimeError("Invalid domain decomposition")
         self.local_grid_size = (self.global_grid_size / self.grid_topology).astype(int)
         self.grid = _Grid(self)
-        pz, py = self.grid_topology[0], self.grid_topology[1]
-        rz, ry = self.rank // py, self.rank % py    # Cartesian order of Create_cart
-        self.rank_z, self.rank_y = rz, ry
-        self.previous_grid_along = np.array([self.rank - py if rz > 0 else PROC_NULL,
-                                             self.rank - 1 if ry > 0 else PROC_NULL, PROC_NULL])
-        self.next_grid_along = np.array([self.rank + py if rz < pz - 1 else PROC_NULL,
-                                         self.rank + 1 if ry < py - 1 else PROC_NULL, PROC_NULL])
+        self.rank_z, self.rank_y = int(self.grid.coords[0]), int(self.grid.coords[1])
+        self.previous_grid_along, self.next_grid_along = _cartesian_neighbours(self.rank, self.grid_topology,
+                                                                               self.periodic_domain)
         self._contexts = {}
 
-    def device_context(self, ghost_size):
-        """The GPU context of this slab for a ghost width (created once, shared by all operators)."""
+    def _require_plain(self, what):
+        if self.general_topology:
+            raise NotImplementedError(_GENERAL_TOPOLOGY.format(what=what, topo=list(self.grid_topology),
+                                                               periodic=self.periodic_domain))
+
+    def device_context(self, ghost_size, exchange_only=False):
+        """The GPU context of this block for a ghost width (created once, shared by all operators)."""
+        if not exchange_only:
+            self._require_plain("device context for operators")
         ctx = self._contexts.get(ghost_size)
         if ctx is None:
+            block = None
+            if self.general_topology:
+                block = (tuple(int(v) for v in self.grid.coords), tuple(int(t) for t in self.grid_topology),
+                         (self.periodic_domain,) * 3)
             ctx = DeviceContext(self.local_grid_size, ghost_size, self.real_t, rank=self.rank, nranks=self.size,
-                                world=self.world, rank_grid=(self.grid_topology[0], self.grid_topology[1]))
+                                world=self.world, rank_grid=(self.grid_topology[0], self.grid_topology[1]), block=block)
             self._start_transport(ctx)
             self._contexts[ghost_size] = ctx
         return ctx
@@ -138,6 +167,7 @@ class MPIConstruct3D:
     def slab_context(self, ghost_size):
         """A second context of this rank, over the z-slab decomposition of the same global grid (the unbounded Poisson
         solve of a pencil decomposition runs there)."""
+        self._require_plain("slab context")
         key = ("slab", ghost_size)
         ctx = self._contexts.get(key)
         if ctx is None:
@@ -183,9 +213,11 @@ def _start_transport(construct, ctx):
 
 
 class MPIGhostCommunicator3D:
-    """utils/mpi_utils_3d.py:86-1142.  ``full_exchange`` is accepted for compatibility: whole faces travel, the z
-    faces first and then the y faces with the fresh z ghost planes in them, so the edges between two
-    neighbours are always filled (z-slabs have no diagonal neighbours at all)."""
+    """utils/mpi_utils_3d.py:86-1142.  On slabs and pencils whole faces travel, the z faces first and then the y faces
+    with the fresh z ghost planes in them, so the edges between two neighbours are always filled (``full_exchange``
+    changes nothing there; z-slabs have no diagonal neighbours at all).  On a general decomposition (x divided, or a
+    periodic domain) the exchange goes axis by axis through ``smi_halo_exchange_general``: faces, and with
+    ``full_exchange`` edges and vertices as well."""
 
     def __init__(self, ghost_size, mpi_construct, full_exchange=True):
         if ghost_size <= 0 or not isinstance(ghost_size, (int, np.integer)):
@@ -193,13 +225,28 @@ class MPIGhostCommunicator3D:
         self.ghost_size = int(ghost_size)
         self.mpi_construct = mpi_construct
         self.full_exchange = full_exchange
-        self.ctx = mpi_construct.device_context(self.ghost_size)
+        self._ctx = mpi_construct.device_context(self.ghost_size, exchange_only=True)
+        self._general = bool(getattr(mpi_construct, "general_topology", False))
+
+    @property
+    def ctx(self):
+        """The device context the operators built on this communicator run on."""
+        self.mpi_construct._require_plain("operators on this ghost communicator")
+        return self._ctx
+
+    def _exchange(self, field, ncomp):
+        if self._general:
+            call("smi_halo_exchange_general", self._ctx.handle, as_ptr(field), int(ncomp), int(bool(self.full_exchange)))
+        else:
+            call(self._entry, self._ctx.handle, as_ptr(field), int(ncomp))
+
+    _entry = "smi_halo_exchange"
 
     def exchange_scalar_field_init(self, local_field):
-        call("smi_halo_exchange", self.ctx.handle, as_ptr(local_field), 1)
+        self._exchange(local_field, 1)
 
     def exchange_vector_field_init(self, local_vector_field):
-        call("smi_halo_exchange", self.ctx.handle, as_ptr(local_vector_field), local_vector_field.shape[0])
+        self._exchange(local_vector_field, local_vector_field.shape[0])
 
     def exchange_finalise(self):
         """Exchanges are stream-ordered with the kernels that consume them; nothing to wait for."""
@@ -218,12 +265,11 @@ class MPIFieldCommunicator3D:
         self.inner_idx = (slice(g, -g),) * dim if g > 0 else (slice(None),) * dim
 
     def _slab(self, rank):
-        """Index of a rank's block in the global (z, y, x) array."""
-        lz, ly = (int(n) for n in self.mpi_construct.local_grid_size[:2])
-        rz, ry = divmod(rank, int(self.mpi_construct.grid_topology[1]))
-        if self.grid_dim == 2:   # (y, x): rows divided, x whole
-            return (slice(rz * lz, (rz + 1) * lz),)
-        return (slice(rz * lz, (rz + 1) * lz), slice(ry * ly, (ry + 1) * ly))
+        """Index of a rank's block in the global (z, y, x) / (y, x) array."""
+        topo = tuple(int(t) for t in self.mpi_construct.grid_topology)
+        coords = np.unravel_index(rank, topo)
+        local = [int(n) for n in self.mpi_construct.local_grid_size]
+        return tuple(slice(c * n, (c + 1) * n) for c, n in zip(coords, local))
 
     def _slab_shape(self):
         return tuple(int(n) for n in self.mpi_construct.local_grid_size)
@@ -295,7 +341,7 @@ class MPILagrangianFieldCommunicator3D:
                 or np.any(cz < 0) or np.any(cy < 0) or np.any(cx < 0)):
             logger.error("Lagrangian node is found outside of Eulerian domain!")
             raise RuntimeError("Lagrangian node is found outside of Eulerian domain!")
-        return (cz * int(topo[1]) + cy).astype(np.int32)   # Cartesian rank of block (cz, cy)
+        return ((cz * int(topo[1]) + cy) * int(topo[2]) + cx).astype(np.int32)   # Cartesian rank of block (cz, cy, cx)
 
     def owner_ranks_of(self, global_lag_positions):
         """Owner rank of every node for these positions (:1386-1394: computed on the master rank, broadcast as M
@@ -371,75 +417,62 @@ __all__ = [
 
 # --------------------------------------------------------------------------- 2D
 class _Grid2D(_Grid):
-    def __init__(self, construct):
-        self._c = construct
-        self.coords = np.array([construct.rank, 0])
+    pass
 
 
 class MPIConstruct2D:
     """utils/mpi_utils_2d.py:9-84.  Several ranks divide the rows (``rank_distribution`` ``[0, 1]``, the reference's
-    default: y distributed, x aligned for the transforms); x is never divided.  Uneven division raises RuntimeError
-    like the reference (:52-58)."""
+    default: y distributed, x aligned for the transforms); the operators keep x whole.  A divided x axis, a fixed rank
+    grid such as ``(2, 2)`` and ``periodic_domain`` are served by the topology and the ghost, field and Lagrangian
+    communicators only, as in 3D.  Uneven division raises RuntimeError like the reference (:52-58)."""
 
     def __init__(self, grid_size_y, grid_size_x, periodic_domain=False, real_t=np.float64, rank_distribution=None,
                  world=None):
         self.grid_dim = 2
         self.real_t = real_t
-        if periodic_domain:
-            raise NotImplementedError("periodic domains are not supported")
-        self.periodic_domain = False
+        self.periodic_domain = bool(periodic_domain)
         self.world = get_world() if world is None else world
         self.size, self.rank = self.world.size, self.world.rank
         self.rank_distribution = [0, 1] if rank_distribution is None else list(rank_distribution)
-        if self.size > 1 and self.rank_distribution[1] != 1:
-            raise NotImplementedError(
-                f"rank_distribution {self.rank_distribution}: the x axis is never divided (row slabs are supported)"
-            )
-        self.grid_topology = [self.size, 1]
+        self.grid_topology = compute_dims(self.size, self.rank_distribution) if self.size > 1 else [1, 1]
+        self.general_topology = self.periodic_domain or self.grid_topology[1] > 1
         self.global_grid_size = np.array((grid_size_y, grid_size_x))
         if np.any(self.global_grid_size % self.grid_topology):
             logger.error("Cannot divide grid evenly to processors in x and/or y directions!")
             raise RuntimeError("Invalid domain decomposition")
         self.local_grid_size = (self.global_grid_size / self.grid_topology).astype(int)
         self.grid = _Grid2D(self)
-        last = self.size - 1
-        self.previous_grid_along = np.array([self.rank - 1 if self.rank > 0 else PROC_NULL, PROC_NULL])
-        self.next_grid_along = np.array([self.rank + 1 if self.rank < last else PROC_NULL, PROC_NULL])
+        self.previous_grid_along, self.next_grid_along = _cartesian_neighbours(self.rank, self.grid_topology,
+                                                                               self.periodic_domain)
         self._contexts = {}
 
-    def device_context(self, ghost_size):
+    _require_plain = MPIConstruct3D._require_plain
+
+    def device_context(self, ghost_size, exchange_only=False):
+        if not exchange_only:
+            self._require_plain("device context for operators")
         ctx = self._contexts.get(ghost_size)
         if ctx is None:
             ny, nx = (int(n) for n in self.local_grid_size)
+            block = None
+            if self.general_topology:
+                cy, cx = (int(v) for v in self.grid.coords)
+                block = ((0, cy, cx), (1, int(self.grid_topology[0]), int(self.grid_topology[1])),
+                         (False, self.periodic_domain, self.periodic_domain))
             ctx = DeviceContext((1, ny, nx), ghost_size, self.real_t, rank=self.rank, nranks=self.size,
-                                world=self.world)
+                                world=self.world, block=block)
             ctx.padded_shape_2d = (ny + 2 * ghost_size, nx + 2 * ghost_size)
             _start_transport(self, ctx)
             self._contexts[ghost_size] = ctx
         return ctx
 
 
-class MPIGhostCommunicator2D:
-    """utils/mpi_utils_2d.py:87-421 for row slabs: the first / last ``ghost_size`` interior rows go to the neighbours'
-    ghost rows (whole padded rows, contiguous in memory).  There are no diagonal neighbours, so ``full_exchange``
-    changes nothing (the reference's own remark, :112-116)."""
+class MPIGhostCommunicator2D(MPIGhostCommunicator3D):
+    """utils/mpi_utils_2d.py:87-421.  Row slabs: the first / last ``ghost_size`` interior rows go to the neighbours'
+    ghost rows (whole padded rows, contiguous in memory; no diagonal neighbours, so ``full_exchange`` changes nothing
+    - the reference's own remark, :112-116).  General decompositions: as in 3D."""
 
-    def __init__(self, ghost_size, mpi_construct, full_exchange=True):
-        if ghost_size <= 0 or not isinstance(ghost_size, (int, np.integer)):
-            raise ValueError(f"Ghost size {ghost_size} needs to be an integer > 0 for calling ghost communication.")
-        self.ghost_size = int(ghost_size)
-        self.mpi_construct = mpi_construct
-        self.full_exchange = full_exchange
-        self.ctx = mpi_construct.device_context(self.ghost_size)
-
-    def exchange_scalar_field_init(self, local_field):
-        call("smi2d_halo_exchange", self.ctx.handle, as_ptr(local_field), 1)
-
-    def exchange_vector_field_init(self, local_vector_field):
-        call("smi2d_halo_exchange", self.ctx.handle, as_ptr(local_vector_field), local_vector_field.shape[0])
-
-    def exchange_finalise(self):
-        """Exchanges are stream-ordered with the kernels that consume them; nothing to wait for."""
+    _entry = "smi2d_halo_exchange"
 
 
 class MPIFieldCommunicator2D(MPIFieldCommunicator3D):

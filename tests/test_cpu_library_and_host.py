@@ -67,8 +67,29 @@ def test_topology_and_errors(smi):
     assert list(p4.previous_grid_along) == [PROC_NULL, 0, PROC_NULL] and list(p4.next_grid_along) == [3, PROC_NULL, PROC_NULL]
     y4 = MPIConstruct3D(16, 8, 8, rank_distribution=(1, 0, 1), world=FakeWorld())
     assert list(y4.grid_topology) == [1, 4, 1] and list(y4.local_grid_size) == [16, 2, 8]
-    with pytest.raises(NotImplementedError):   # x is never divided
-        MPIConstruct3D(16, 8, 8, rank_distribution=(0, 0, 0), world=FakeWorld())
+    # nothing aligned: MPI.Compute_dims spreads 4 ranks as 2 x 2 x 1, which leaves x whole
+    f4 = MPIConstruct3D(16, 8, 8, rank_distribution=(0, 0, 0), world=FakeWorld())
+    assert list(f4.grid_topology) == [2, 2, 1] and not f4.general_topology
+    # a divided x axis and a periodic domain (what the reference's own communicator tests run on,
+    # tests/test_utils/test_mpi_utils_3d.py:95-125): the topology is served, the operators are not
+    x4 = MPIConstruct3D(16, 8, 8, rank_distribution=(1, 1, 0), world=FakeWorld())
+    assert list(x4.grid_topology) == [1, 1, 4] and list(x4.local_grid_size) == [16, 8, 2] and x4.general_topology
+    assert list(x4.grid.coords) == [0, 0, 1]
+    assert list(x4.previous_grid_along) == [PROC_NULL, PROC_NULL, 0] and list(x4.next_grid_along) == [PROC_NULL, PROC_NULL, 2]
+    with pytest.raises(NotImplementedError):
+        x4.device_context(2)
+    with pytest.raises(NotImplementedError):
+        x4.slab_context(2)
+    per = MPIConstruct3D(16, 8, 8, periodic_domain=True, rank_distribution=(0, 0, 1), world=FakeWorld())
+    assert per.general_topology and list(per.grid_topology) == [2, 2, 1] and list(per.grid.coords) == [0, 1, 0]
+    # Cart_shift on periodic axes wraps; an axis with one rank wraps onto the rank itself
+    assert list(per.previous_grid_along) == [3, 0, 1] and list(per.next_grid_along) == [3, 0, 1]
+
+    class LastOfFour(SingleWorld):
+        rank, size = 3, 4
+
+    wrap = MPIConstruct3D(16, 8, 8, periodic_domain=True, rank_distribution=(0, 1, 1), world=LastOfFour())
+    assert list(wrap.previous_grid_along) == [2, 3, 3] and list(wrap.next_grid_along) == [0, 3, 3]
     with pytest.raises(ValueError):  # utils/mpi_utils.py:17-24
         check_valid_ghost_size_and_kernel_support(ghost_size=1, kernel_support=2)
 
@@ -190,8 +211,20 @@ def test_2d_row_slab_topology_and_owner_map(smi):
     assert list(c.previous_grid_along) == [1, PROC_NULL] and list(c.next_grid_along) == [3, PROC_NULL]
     with pytest.raises(RuntimeError):           # :52-58
         MPIConstruct2D(30, 24, world=FakeWorld())
-    with pytest.raises(NotImplementedError):    # x is never divided
-        MPIConstruct2D(32, 24, rank_distribution=[1, 0], world=FakeWorld())
+    # columns divided, a fixed 2 x 2 grid, a periodic plane (tests/test_utils/test_mpi_utils_2d.py:81-101): topology
+    # and communicators only
+    cols = MPIConstruct2D(32, 24, rank_distribution=[1, 0], world=FakeWorld())
+    assert list(cols.grid_topology) == [1, 4] and list(cols.local_grid_size) == [32, 6] and cols.general_topology
+    assert list(cols.grid.coords) == [0, 2] and list(cols.previous_grid_along) == [PROC_NULL, 1]
+    with pytest.raises(NotImplementedError):
+        cols.device_context(2)
+    quad = MPIConstruct2D(32, 24, periodic_domain=True, rank_distribution=[2, 2], world=FakeWorld())
+    assert list(quad.grid_topology) == [2, 2] and list(quad.grid.coords) == [1, 0]
+    assert list(quad.previous_grid_along) == [0, 3] and list(quad.next_grid_along) == [0, 3]
+    owner = MPILagrangianFieldCommunicator2D(1.0 / 24, 0.5 / 24, quad)
+    # (x, y) positions: the block of a node is (row block, column block), its rank row-major over the grid
+    nodes = np.array([[0.1, 0.9, 0.1, 0.9], [0.1, 0.1, 1.2, 1.2]])
+    assert list(owner._compute_lag_nodes_rank_address(nodes)) == [0, 1, 2, 3]
     dx = np.float32(1.0 / 24)
     comm = MPILagrangianFieldCommunicator2D(dx, np.float32(dx / 2), c, master_rank=2)   # this (fake) rank maps
     pos = np.random.default_rng(2).uniform(0.05, 0.95, (2, 200)) * np.array([1.0, 32 / 24]).reshape(2, 1)

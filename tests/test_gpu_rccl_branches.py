@@ -66,6 +66,12 @@ def test_row_slab_2d_flow_over_the_rccl_branches(nranks, flow_type, mode, grid):
     _run("_rows_worker_2d.py", nranks, 29900 + nranks, [flow_type, mode] + grid.split())
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+def test_general_topology_exchange_over_the_rccl_branches(dim):
+    """The axis-by-axis ghost exchange of general decompositions (x divided, periodic) as ncclSend / ncclRecv groups."""
+    _run("_ghost_topology_worker.py", 4, 29930 + dim, [str(dim), "quick"])
+
+
 @pytest.mark.parametrize("nranks,grid,precision", [(2, "16x16x24", "single"), (4, "16x32x24", "double"),
                                                    (8, "32x32x16", "single")])
 def test_fft_and_doubled_domain_types_over_the_rccl_branches(nranks, grid, precision):

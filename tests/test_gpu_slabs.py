@@ -141,3 +141,20 @@ def test_bench_starts_its_own_ranks():
     env["WORLD_SIZE"] = "1"
     bad = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.parametrize("dim,nranks", [(3, 4), (2, 4), (3, 8)])
+def test_communicators_on_general_topologies(dim, nranks):
+    """Topology, ghost, field and Lagrangian communicators on every rank distribution of the reference's own
+    communicator tests (tests/test_utils/test_mpi_utils_3d.py:14-125, test_mpi_utils_2d.py:14-101): x divided,
+    periodic domains, faces and - with full_exchange - edges and vertices, both precisions, ghost sizes 1 and 2."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["SOPHT_MI_TRANSPORT"] = "host"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(29800 + 10 * dim + nranks),
+           os.path.join(ROOT, "tests", "_ghost_topology_worker.py"), str(dim)] + (["quick"] if nranks == 8 else [])
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, _failure_digest(out)
+    for r in range(nranks):
+        assert f"rank {r} ok" in out.stdout
