@@ -206,6 +206,22 @@ int smi_diffusion_timestep(smi_ctx* ctx, void* field, void* flux, double nu_dt_b
  * update_vorticity_from_velocity_forcing_mpi_3d.py:9-178 */
 int smi_update_vorticity_from_velocity_forcing(smi_ctx* ctx, void* vorticity, void* forcing,
                                                double prefactor);
+/* gen_update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d
+ * (stencil_ops_3d/update_vorticity_from_velocity_forcing_mpi_3d.py:181-330):
+ * vorticity += prefactor * curl(penalised_velocity - velocity) on the same cells; both inputs are exchanged first. */
+int smi_update_vorticity_from_penalised_velocity(smi_ctx* ctx, void* vorticity, void* penalised_velocity,
+                                                 void* velocity, double prefactor);
+/* Pointwise helpers of the penalisation method, kernel support 0 (every cell of the arrays, ghost cells included,
+ * no exchange; a 2D context takes its plane).  gen_brinkmann_penalise_pyst_mpi_kernel_3d / _2d
+ * (stencil_ops_3d/brinkmann_penalise_mpi_3d.py:7-19): penalised = (field + lambda chi penalty) / (1 + lambda chi) for
+ * ncomp components sharing the one-component char_field.
+ * gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_3d / _2d
+ * (stencil_ops_3d/char_func_from_level_set_mpi_3d.py:8-28): chi = 0 below -blend_width, 1 above blend_width,
+ * (1 + phi / w + sin(pi phi / w) / pi) / 2 in between.  The bodies of both are in the sopht package, which the
+ * reference tree does not hold: the formulas are the published ones of that method. */
+int smi_brinkmann_penalise(smi_ctx* ctx, void* penalised_field, const void* field, const void* char_field,
+                           const void* penalty_field, double penalty_factor, int ncomp);
+int smi_char_func_from_level_set(smi_ctx* ctx, void* char_func_field, const void* level_set_field, double blend_width);
 /* The rotational-form advection of rotational_form_navier_stokes_timestep in one pass
  * (flow_simulators_mpi_3d.py:395-405: elementwise_cross_product(buffer, velocity, vorticity) then
  * update_vorticity_from_velocity_forcing(vorticity, buffer, dt / (2 dx))), written to another array:

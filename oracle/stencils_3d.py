@@ -178,6 +178,31 @@ def update_vorticity_from_velocity_forcing(vorticity, forcing, prefactor, g):
         _update_vorticity_body(vorticity[full + box], forcing[full + box], prefactor)
 
 
+def update_vorticity_from_penalised_velocity(vorticity, penalised_velocity, velocity, prefactor, g):
+    """update_vorticity_from_velocity_forcing_mpi_3d.py:181-330: w += prefactor * curl(u_pen - u) on the same
+    seven boxes (the stencil body is in sopht: the difference is formed value by value, parity unpinned)."""
+    update_vorticity_from_velocity_forcing(vorticity, penalised_velocity - velocity, prefactor, g)
+
+
+def brinkmann_penalise(penalised, penalty_factor, char_field, penalty_field, field):
+    """sopht gen_brinkmann_penalise_pyst_kernel_3d / 2d (call site brinkmann_penalise_mpi_3d.py:7-19): implicit
+    Brinkmann penalisation on the whole array, scalar or vector fields sharing one characteristic function.
+    Body not in the reference tree (parity unpinned): the standard form of the method."""
+    dtype = field.dtype.type
+    lam = dtype(penalty_factor)
+    penalised[...] = (field + lam * char_field * penalty_field) / (dtype(1) + lam * char_field)
+
+
+def char_func_from_level_set_via_sine_heaviside(char_func, level_set, blend_width):
+    """sopht gen_char_func_from_level_set_via_sine_heaviside_pyst_kernel_3d / 2d (call site
+    char_func_from_level_set_mpi_3d.py:8-28): smooth sine Heaviside function of the level set, whole array.
+    Body not in the reference tree (parity unpinned)."""
+    dtype = level_set.dtype.type
+    w = dtype(blend_width)
+    smooth = dtype(0.5) * (dtype(1) + level_set / w + np.sin(dtype(np.pi) * level_set / w) / dtype(np.pi))
+    char_func[...] = np.where(level_set < -w, dtype(0), np.where(level_set > w, dtype(1), smooth))
+
+
 def curl(curl_field, field, prefactor, g, phys=ALL_PHYS):
     """curl_mpi_3d.py:29-194."""
     full = (slice(None),)

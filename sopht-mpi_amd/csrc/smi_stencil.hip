@@ -223,10 +223,25 @@ struct CurlRange {
   long long q_begin, q_end;
   int z_begin, z_end;
 };
-template <typename T, int V, int MODE>
+// DIFF: the curl of f - h (update_vorticity_from_penalised_velocity: f the penalised velocity, h the velocity), the
+// difference formed as each value is loaded.
+template <typename T, int V, int MODE, bool DIFF = false>
 __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f, T pref, Geo G, int zchunk,
-                                                 CurlRange R) {
+                                                 CurlRange R, const T* __restrict__ h = nullptr) {
   const Blk B = xcd_block<false>();
+  auto ldv = [&](const T* p) {
+    Pack<T, V> a = ld<T, V>(p);
+    if constexpr (DIFF) {
+      const Pack<T, V> b = ld<T, V>(h + (p - f));
+#pragma unroll
+      for (int e = 0; e < V; ++e) a.v[e] -= b.v[e];
+    }
+    return a;
+  };
+  auto ld1 = [&](const T* p) {
+    if constexpr (DIFF) return p[0] - h[p - f];
+    else return p[0];
+  };
   const long long q = R.q_begin + ((long long)B.x * blockDim.x + threadIdx.x) * V;
   if (q >= R.q_end) return;
   const int y = (int)(q / G.px), x0 = (int)(q - (long long)y * G.px);
@@ -270,16 +285,16 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
     return;
   }
   for (int z = z0; z < zs; ++z) outside(z);
-  Pack<T, V> fx_prev = ld<T, V>(fx + (zs - 1) * G.plane), fx_cur = ld<T, V>(fx + zs * G.plane);
-  Pack<T, V> fy_prev = ld<T, V>(fy + (zs - 1) * G.plane), fy_cur = ld<T, V>(fy + zs * G.plane);
+  Pack<T, V> fx_prev = ldv(fx + (zs - 1) * G.plane), fx_cur = ldv(fx + zs * G.plane);
+  Pack<T, V> fy_prev = ldv(fy + (zs - 1) * G.plane), fy_cur = ldv(fy + zs * G.plane);
   for (int z = zs; z <= ze; ++z) {
     const long long zo = z * G.plane;
-    Pack<T, V> fx_nxt = ld<T, V>(fx + zo + G.plane), fy_nxt = ld<T, V>(fy + zo + G.plane);
-    Pack<T, V> fx_ym = ld<T, V>(fx + zo - G.px), fx_yp = ld<T, V>(fx + zo + G.px);
-    Pack<T, V> fz_ym = ld<T, V>(fz + zo - G.px), fz_yp = ld<T, V>(fz + zo + G.px);
-    Pack<T, V> fz_c = ld<T, V>(fz + zo);
-    T fy_xm = fy[zo - 1], fy_xp = fy[zo + V];
-    T fz_xm = fz[zo - 1], fz_xp = fz[zo + V];
+    Pack<T, V> fx_nxt = ldv(fx + zo + G.plane), fy_nxt = ldv(fy + zo + G.plane);
+    Pack<T, V> fx_ym = ldv(fx + zo - G.px), fx_yp = ldv(fx + zo + G.px);
+    Pack<T, V> fz_ym = ldv(fz + zo - G.px), fz_yp = ldv(fz + zo + G.px);
+    Pack<T, V> fz_c = ldv(fz + zo);
+    T fy_xm = ld1(fy + zo - 1), fy_xp = ld1(fy + zo + V);
+    T fz_xm = ld1(fz + zo - 1), fz_xp = ld1(fz + zo + V);
     Pack<T, V> rx, ry, rz;
     bool m[V], anym = false;
     const bool zA = z >= G.g && z <= G.pz - G.g - 1;
@@ -1569,6 +1584,89 @@ extern "C" int smi_update_vorticity_from_velocity_forcing(smi_ctx* c, void* vort
                                                           double prefactor) {
   SMI_REQUIRE(c && vorticity && forcing, "smi_update_vorticity_from_velocity_forcing: bad argument");
   return run_curl<1>(c, vorticity, forcing, prefactor);
+}
+
+// gen_update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d
+// (update_vorticity_from_velocity_forcing_mpi_3d.py:181-330): vorticity += p * curl(penalised_velocity - velocity) on
+// the update set of smi_update_vorticity_from_velocity_forcing, both inputs exchanged first.
+extern "C" int smi_update_vorticity_from_penalised_velocity(smi_ctx* c, void* vorticity, void* penalised_velocity,
+                                                            void* velocity, double prefactor) {
+  SMI_REQUIRE(c && vorticity && penalised_velocity && velocity,
+              "smi_update_vorticity_from_penalised_velocity: bad argument");
+  SMI_REQUIRE(vorticity != penalised_velocity && vorticity != velocity,
+              "smi_update_vorticity_from_penalised_velocity: the vorticity must not alias its inputs");
+  if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange2_impl(c, velocity, 3, penalised_velocity, 3));
+  Geo G = make_geo(c);
+  SmiProfScope prof(c, PROF_CURL_UPDATE, 12.0 * smi_S(c));
+  SMI_DISPATCH(c, {
+    const CurlRange R{0, G.plane, 0, G.pz};
+    if (vec_ok<T>(c, vorticity, penalised_velocity) && vec_ok<T>(c, vorticity, velocity)) {
+      LaunchShape s = plan<4>(c, 1);
+      k_curl<T, 4, 1, true><<<s.grid, kBlock, 0, c->stream>>>((T*)vorticity, (const T*)penalised_velocity, (T)prefactor,
+                                                             G, s.zchunk, R, (const T*)velocity);
+    } else {
+      LaunchShape s = plan<1>(c, 1);
+      k_curl<T, 1, 1, true><<<s.grid, kBlock, 0, c->stream>>>((T*)vorticity, (const T*)penalised_velocity, (T)prefactor,
+                                                             G, s.zchunk, R, (const T*)velocity);
+    }
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- pointwise helpers of the penalisation method
+// gen_brinkmann_penalise_pyst_mpi_kernel_3d / 2d (brinkmann_penalise_mpi_3d.py:7-19): implicit Brinkmann
+// penalisation, penalised = (field + lambda chi penalty) / (1 + lambda chi), on every cell of the arrays (kernel
+// support 0: no exchange, ghost cells included); n cells per component, ncomp components, chi one component.
+// gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_3d / 2d (char_func_from_level_set_mpi_3d.py:8-28):
+// chi = 0 below -w, 1 above w, (1 + phi / w + sin(pi phi / w) / pi) / 2 in between.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_brinkmann(T* __restrict__ out, const T* __restrict__ f,
+                                                      const T* __restrict__ chi, const T* __restrict__ pen, T lambda,
+                                                      long long n, int ncomp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T lc = lambda * chi[i];
+  for (int k = 0; k < ncomp; ++k) out[k * n + i] = (f[k * n + i] + lc * pen[k * n + i]) / (T(1) + lc);
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_sine_heaviside(T* __restrict__ chi, const T* __restrict__ phi, T w,
+                                                           long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T p = phi[i];
+  const T pi = (T)3.14159265358979323846;
+  T v = T(0.5) * (T(1) + p / w + sin(pi * p / w) / pi);
+  v = p < -w ? T(0) : (p > w ? T(1) : v);
+  chi[i] = v;
+}
+}  // namespace
+
+extern "C" int smi_brinkmann_penalise(smi_ctx* c, void* penalised_field, const void* field, const void* char_field,
+                                      const void* penalty_field, double penalty_factor, int ncomp) {
+  SMI_REQUIRE(c && penalised_field && field && char_field && penalty_field && ncomp >= 1 && ncomp <= 3,
+              "smi_brinkmann_penalise: bad argument");
+  const long long n = c->nz == 1 ? (long long)c->plane : (long long)c->vol;
+  SMI_DISPATCH(c, {
+    k_brinkmann<T><<<blocks_for(n), kBlock, 0, c->stream>>>((T*)penalised_field, (const T*)field, (const T*)char_field,
+                                                           (const T*)penalty_field, (T)penalty_factor, n, ncomp);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int smi_char_func_from_level_set(smi_ctx* c, void* char_func_field, const void* level_set_field,
+                                            double blend_width) {
+  SMI_REQUIRE(c && char_func_field && level_set_field, "smi_char_func_from_level_set: bad argument");
+  SMI_REQUIRE(blend_width > 0.0, "smi_char_func_from_level_set: the blend width must be positive");
+  const long long n = c->nz == 1 ? (long long)c->plane : (long long)c->vol;
+  SMI_DISPATCH(c, {
+    k_sine_heaviside<T><<<blocks_for(n), kBlock, 0, c->stream>>>((T*)char_func_field, (const T*)level_set_field,
+                                                                (T)blend_width, n);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
 }
 
 // out = vorticity + p * curl(velocity x vorticity) on the update set, vorticity elsewhere

@@ -56,6 +56,9 @@ SIGNATURES = {
     "smi_set_sendrecv_callback": [_p, SENDRECV_CB],
     "smi_set_group_alltoall_callback": [_p, GROUP_ALLTOALL_CB],
     "smi_set_p2p_callback": [_p, P2P_CB],
+    "smi_update_vorticity_from_penalised_velocity": [_p, _p, _p, _p, _d],
+    "smi_brinkmann_penalise": [_p, _p, _p, _p, _p, _d, _i],
+    "smi_char_func_from_level_set": [_p, _p, _p, _d],
     "smi_ctx_set_block": [_p, _p, _p, _p],
     "smi_ctx_create_block": [_pp, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "smi_halo_exchange_general": [_p, _p, _i, _i],

@@ -126,6 +126,67 @@ def gen_update_vorticity_from_velocity_forcing_pyst_mpi_kernel_3d(real_t, mpi_co
                     update_vorticity_from_velocity_forcing_pyst_mpi_kernel_3d, 1, ghost_exchange_communicator)
 
 
+def gen_update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d(real_t, mpi_construct,
+                                                                    ghost_exchange_communicator):
+    """stencil_ops_3d/update_vorticity_from_velocity_forcing_mpi_3d.py:181-330:
+    vorticity_field += prefactor * curl(penalised_velocity_field - velocity_field)."""
+    ctx = ghost_exchange_communicator.ctx
+
+    def update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d(vorticity_field, penalised_velocity_field,
+                                                                    velocity_field, prefactor):
+        call("smi_update_vorticity_from_penalised_velocity", ctx.handle, as_ptr(vorticity_field),
+             as_ptr(penalised_velocity_field), as_ptr(velocity_field), float(prefactor))
+
+    return _support(gen_update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d,
+                    update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d, 1, ghost_exchange_communicator)
+
+
+def _gen_brinkmann_penalise(gen, field_type, ncomp_vector):
+    _check_field_type(field_type)
+    gen.kernel_support = 0
+
+    if field_type == "scalar":
+
+        def brinkmann_penalise(penalised_field, penalty_factor, char_field, penalty_field, field):
+            call("smi_brinkmann_penalise", field.ctx.handle, as_ptr(penalised_field), as_ptr(field), as_ptr(char_field),
+                 as_ptr(penalty_field), float(penalty_factor), 1)
+
+    else:
+
+        def brinkmann_penalise(penalised_vector_field, penalty_factor, char_field, penalty_vector_field, vector_field):
+            call("smi_brinkmann_penalise", vector_field.ctx.handle, as_ptr(penalised_vector_field),
+                 as_ptr(vector_field), as_ptr(char_field), as_ptr(penalty_vector_field), float(penalty_factor),
+                 ncomp_vector)
+
+    brinkmann_penalise.kernel_support = 0
+    return brinkmann_penalise
+
+
+def gen_brinkmann_penalise_pyst_mpi_kernel_3d(real_t, field_type="scalar"):
+    """stencil_ops_3d/brinkmann_penalise_mpi_3d.py:7-19: pointwise (kernel support 0, no exchange),
+    penalised = (field + penalty_factor * char_field * penalty_field) / (1 + penalty_factor * char_field)."""
+    return _gen_brinkmann_penalise(gen_brinkmann_penalise_pyst_mpi_kernel_3d, field_type, 3)
+
+
+def _gen_char_func(gen, blend_width):
+    gen.kernel_support = 0
+    if blend_width <= 0:
+        raise ValueError("blend_width must be positive")
+
+    def char_func_from_level_set_via_sine_heaviside(char_func_field, level_set_field):
+        call("smi_char_func_from_level_set", level_set_field.ctx.handle, as_ptr(char_func_field),
+             as_ptr(level_set_field), float(blend_width))
+
+    char_func_from_level_set_via_sine_heaviside.kernel_support = 0
+    return char_func_from_level_set_via_sine_heaviside
+
+
+def gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_3d(blend_width, real_t):
+    """stencil_ops_3d/char_func_from_level_set_mpi_3d.py:8-28: characteristic function of a body from its level set
+    through the smooth sine Heaviside function (0 below -blend_width, 1 above, pointwise)."""
+    return _gen_char_func(gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_3d, blend_width)
+
+
 def gen_curl_pyst_mpi_kernel_3d(real_t, mpi_construct, ghost_exchange_communicator):
     """stencil_ops_3d/curl_mpi_3d.py:10-196."""
     ctx = ghost_exchange_communicator.ctx

@@ -16,6 +16,20 @@ def _support(gen, fn, kernel_support, ghost_exchange_communicator):
     return fn
 
 
+def gen_brinkmann_penalise_pyst_mpi_kernel_2d(real_t, field_type="scalar"):
+    """stencil_ops_2d/brinkmann_penalise_mpi_2d.py:7-19 (pointwise, kernel support 0)."""
+    from . import _gen_brinkmann_penalise
+
+    return _gen_brinkmann_penalise(gen_brinkmann_penalise_pyst_mpi_kernel_2d, field_type, 2)
+
+
+def gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_2d(blend_width, real_t):
+    """stencil_ops_2d/char_func_from_level_set_mpi_2d.py:8-28 (pointwise, kernel support 0)."""
+    from . import _gen_char_func
+
+    return _gen_char_func(gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_2d, blend_width)
+
+
 def gen_diffusion_flux_pyst_mpi_kernel_2d(real_t, mpi_construct, ghost_exchange_communicator):
     """stencil_ops_2d/diffusion_flux_mpi_2d.py."""
     ctx = ghost_exchange_communicator.ctx

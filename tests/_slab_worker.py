@@ -132,6 +132,27 @@ if fused and (n[2] + 2 * g) % 4 == 0:
     # the one-call step took the one-pass advection + diffusion kernel on every step (slabs and pencils alike)
     launched = _lib.prof_collect(gpu.ctx).get("fused_advect_diffuse", {"launches": 0})["launches"]
     assert launched >= 4, f"one-pass advection + diffusion kernel launched {launched} times in 4 steps"
+if flow_type == "navier_stokes":
+    # w += p curl(u_pen - u) across the ranks (update_vorticity_from_velocity_forcing_mpi_3d.py:181-330): interiors
+    # scattered, both inputs exchanged by the operator, against the oracle on the whole grid
+    from oracle import stencils_3d as st3  # noqa: E402
+    from sopht_mpi_amd.numeric import eulerian_grid_ops as ops  # noqa: E402
+
+    update = ops.gen_update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d(
+        real_t, gpu.mpi_construct, gpu.mpi_ghost_exchange_communicator)
+    glob = rng.standard_normal((3, 3) + n).astype(real_t)   # velocity, penalised velocity, vorticity
+    fields = [gpu.ctx.field(3) for _ in range(3)]
+    for k in range(3):
+        comm.scatter_global_vector_field(fields[k], glob[k] if rank == 0 else None)
+    update(vorticity_field=fields[2], penalised_velocity_field=fields[1], velocity_field=fields[0], prefactor=real_t(0.37))
+    got = np.zeros((3,) + n, dtype=real_t) if rank == 0 else None
+    comm.gather_local_vector_field(got, fields[2])
+    if rank == 0:
+        padded = [np.zeros((3,) + tuple(v + 2 * g for v in n), dtype=real_t) for _ in range(3)]
+        for k in range(3):
+            padded[k][inner] = glob[k]
+        st3.update_vorticity_from_penalised_velocity(padded[2], padded[1], padded[0], real_t(0.37), g)
+        assert_close(got, padded[2][inner], real_t, what="update from penalised velocity across ranks")
 mv = gpu.get_max_vorticity()
 assert abs(float(mv) - float(cpu.get_max_vorticity())) <= 1e-5 * abs(float(cpu.get_max_vorticity()))
 world.barrier()

@@ -63,6 +63,27 @@ def test_2d_operators(smi, shape, g, real_t):
     assert real_t(out.value) == np.sum(np.fabs(vel), axis=0)[g:-g, g:-g].max()
     call("smi2d_reduce_max", ctx.handle, df.ptr, C.byref(out))
     assert real_t(out.value) == wf[g:-g, g:-g].max()
+    # the pointwise operators of the penalisation method (stencil_ops_2d/brinkmann_penalise_mpi_2d.py,
+    # char_func_from_level_set_mpi_2d.py), on the plane of a 2D context
+    from oracle import stencils_3d as st3
+    from sopht_mpi_amd.numeric import eulerian_grid_ops as ops
+
+    chi, pen = rng.random(pshape).astype(real_t), rand_field(rng, (2,) + pshape, real_t)
+    brinkmann = ops.gen_brinkmann_penalise_pyst_mpi_kernel_2d(real_t=real_t, field_type="vector")
+    dout = ctx.from_numpy(np.ones((2,) + pshape, dtype=real_t))
+    brinkmann(penalised_vector_field=dout, penalty_factor=real_t(0.3), char_field=ctx.from_numpy(chi),
+              penalty_vector_field=ctx.from_numpy(pen), vector_field=dvel)
+    want2 = np.ones((2,) + pshape, dtype=real_t)
+    st3.brinkmann_penalise(want2, real_t(0.3), chi, pen, vel)
+    assert_close(dout.get(), want2, real_t, what="2D Brinkmann penalisation")
+    heaviside = ops.gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_2d(blend_width=0.15, real_t=real_t)
+    phi = (rng.random(pshape) - 0.5).astype(real_t)
+    dchi = ctx.zeros(pshape)
+    heaviside(char_func_field=dchi, level_set_field=ctx.from_numpy(phi))
+    wchi = np.zeros_like(phi)
+    st3.char_func_from_level_set_via_sine_heaviside(wchi, phi, real_t(0.15))
+    assert_close(dchi.get(), wchi, real_t, scale=1.0, factor=4.0, what="2D characteristic function")
+    assert brinkmann.kernel_support == 0 and heaviside.kernel_support == 0
 
 
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])

@@ -102,6 +102,64 @@ def test_diffusion_flux_and_timestep(smi, shape, g, real_t):
 
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
 @pytest.mark.parametrize("shape,g", CASES)
+def test_penalisation_method_operators(smi, shape, g, real_t):
+    """gen_update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d, gen_brinkmann_penalise_pyst_mpi_kernel_3d and
+    gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_3d through the package's generators, as the
+    reference's tests call them (test_update_vorticity_from_velocity_forcing_mpi_3d.py:142-260,
+    test_brinkmann_penalise_mpi_3d.py, test_char_func_from_level_set_mpi_3d.py)."""
+    from sopht_mpi_amd.numeric import eulerian_grid_ops as ops
+    from sopht_mpi_amd.utils import MPIConstruct3D, MPIGhostCommunicator3D
+    from sopht_mpi_amd.world import SingleWorld
+
+    rng = np.random.default_rng(17)
+    construct = MPIConstruct3D(*shape, real_t=real_t, world=SingleWorld())
+    ghost_comm = MPIGhostCommunicator3D(ghost_size=g, mpi_construct=construct)
+    ctx = ghost_comm.ctx
+    full = (3,) + ctx.padded_shape
+    u, up, w = (rand_field(rng, full, real_t) for _ in range(3))
+    p = real_t(0.41)
+    update = ops.gen_update_vorticity_from_penalised_velocity_pyst_mpi_kernel_3d(real_t, construct, ghost_comm)
+    assert update.kernel_support == 1
+    du, dup, dw = ctx.from_numpy(u), ctx.from_numpy(up), ctx.from_numpy(w)
+    update(vorticity_field=dw, penalised_velocity_field=dup, velocity_field=du, prefactor=p)
+    want = w.copy()
+    st.update_vorticity_from_penalised_velocity(want, up, u, p, g)
+    assert_close(dw.get(), want, real_t, what="update from penalised velocity")
+    untouched = want == w
+    assert np.array_equal(dw.get()[untouched], w[untouched])
+
+    chi = rng.random(ctx.padded_shape).astype(real_t)
+    for field_type, shape_f in (("scalar", ctx.padded_shape), ("vector", full)):
+        brinkmann = ops.gen_brinkmann_penalise_pyst_mpi_kernel_3d(real_t=real_t, field_type=field_type)
+        assert brinkmann.kernel_support == 0
+        f, pen = rand_field(rng, shape_f, real_t), rand_field(rng, shape_f, real_t)
+        out = ctx.from_numpy(np.ones(shape_f, dtype=real_t))
+        names = ("penalised_field", "penalty_field", "field") if field_type == "scalar" else (
+            "penalised_vector_field", "penalty_vector_field", "vector_field")
+        brinkmann(**{names[0]: out, "penalty_factor": real_t(0.1), "char_field": ctx.from_numpy(chi),
+                     names[1]: ctx.from_numpy(pen), names[2]: ctx.from_numpy(f)})
+        want = np.ones(shape_f, dtype=real_t)
+        st.brinkmann_penalise(want, real_t(0.1), chi, pen, f)
+        assert_close(out.get(), want, real_t, what=f"brinkmann penalisation ({field_type})")
+    with pytest.raises(ValueError):
+        ops.gen_brinkmann_penalise_pyst_mpi_kernel_3d(real_t=real_t, field_type="tensor")
+
+    heaviside = ops.gen_char_func_from_level_set_via_sine_heaviside_pyst_mpi_kernel_3d(blend_width=real_t(0.2),
+                                                                                        real_t=real_t)
+    assert heaviside.kernel_support == 0
+    phi = (rng.random(ctx.padded_shape) - 0.5).astype(real_t)   # both plateaus and the blend zone
+    out = ctx.field()
+    heaviside(char_func_field=out, level_set_field=ctx.from_numpy(phi))
+    want = np.zeros_like(phi)
+    st.char_func_from_level_set_via_sine_heaviside(want, phi, real_t(0.2))
+    assert_close(out.get(), want, real_t, scale=1.0, factor=4.0, what="sine Heaviside characteristic function")
+    got = out.get()
+    # (rounding at the ends of the blend zone may leave the plateau values by a few units in the last place)
+    assert np.all(got[phi < -0.2] == 0) and np.all(got[phi > 0.2] == 1) and got.min() >= -1e-6 and got.max() <= 1 + 1e-6
+
+
+@pytest.mark.parametrize("real_t", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,g", CASES)
 def test_curl_update_divergence(smi, shape, g, real_t):
     rng = np.random.default_rng(3)
     ctx = make_ctx(smi, shape, g, real_t)
