@@ -132,9 +132,11 @@ class SequentialWorld(SingleWorld):
 
 @pytest.mark.parametrize("ghost_size", [1, 2])
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
-@pytest.mark.parametrize("rank_distribution,size", [((0, 1, 1), 1), ((0, 1, 1), 4), ((1, 0, 1), 2), ((0, 0, 1), 4)])
+@pytest.mark.parametrize("rank_distribution,size", [((0, 1, 1), 1), ((0, 1, 1), 4), ((1, 0, 1), 2), ((0, 0, 1), 4),
+                                                    ((1, 1, 0), 4), ((1, 0, 0), 4), ((0, 1, 0), 4)])
 def test_eulerian_fields_round_trip_3d(smi, tmp_path, ghost_size, real_t, rank_distribution, size):
-    """test_mpi_io_3d.py:11-250: scalar and vector fields, every decomposition served here, both precisions."""
+    """test_mpi_io_3d.py:11-250: scalar and vector fields, every rank distribution of the reference's test (a divided x
+    axis included), both precisions."""
     from sopht_mpi_amd.utils import MPIIO, MPIConstruct3D
 
     rng = np.random.default_rng(3)
@@ -155,9 +157,7 @@ def test_eulerian_fields_round_trip_3d(smi, tmp_path, ghost_size, real_t, rank_d
         return c, io
 
     def block(c):
-        lz, ly, lx = (int(n) for n in c.local_grid_size)
-        rz, ry = int(c.grid.coords[0]), int(c.grid.coords[1])
-        return (slice(rz * lz, (rz + 1) * lz), slice(ry * ly, (ry + 1) * ly), slice(0, lx))
+        return tuple(slice(int(r) * int(n), (int(r) + 1) * int(n)) for r, n in zip(c.grid.coords, c.local_grid_size))
 
     inner = (slice(g, -g),) * 3
     for rank in range(size):
