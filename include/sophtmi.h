@@ -104,6 +104,12 @@ int smi_set_alltoall_callback(smi_ctx* ctx, smi_alltoall_cb cb);
  * Host-staged transports for tests: a pairwise exchange of device buffers with the two y neighbours
  * (peer -1 = none) and an all-to-all of equal blocks inside a group of `count` consecutive ranks. */
 int smi_ctx_set_pencil(smi_ctx* ctx, int rank_z, int nranks_z, int rank_y, int nranks_y);
+/* The same with x divided as well (rank_distribution (1, 1, 0), (1, 0, 0), (0, 1, 0) of the reference's operator
+ * tests): rank = (rank_z * nranks_y + rank_y) * nranks_x + rank_x, nz / ny / nx of smi_ctx_create the local sizes of
+ * the block.  Exchanges add the x faces (packed columns), the zero bands of the operators apply on physical x faces
+ * only, the Poisson solve is routed through z-slabs as for pencils.  Kernels that work on 16-byte row vectors fall
+ * back to their scalar forms when the local row (nx + 2 ghost) is no multiple of four. */
+int smi_ctx_set_grid3(smi_ctx* ctx, int rank_z, int nranks_z, int rank_y, int nranks_y, int rank_x, int nranks_x);
 typedef int (*smi_sendrecv_cb)(void* user, int peer_lo, int peer_hi, const void* send_lo, const void* send_hi,
                                void* recv_lo, void* recv_hi, size_t bytes);
 int smi_set_sendrecv_callback(smi_ctx* ctx, smi_sendrecv_cb cb);

@@ -78,28 +78,74 @@ static int rows_copy(smi_ctx* c, void* field, void* buf, int ncomp, int d, int y
   return 0;
 }
 
-// Exchange with the two y neighbours (rank -/+ 1 inside the row of nranks_y ranks).
-// Halo (sum = false): my first / last d interior rows -> the neighbour's ghost rows next to its interior
-// (MPIGhostCommunicator3D, y faces).  Ghost sum (sum = true, d = g): my ghost rows are added to the neighbour's
-// edge interior rows (MPIGhostSumCommunicator3D.ghost_sum, the two y steps).
-int smi_y_face_exchange(smi_ctx* c, void* field, int ncomp, int d, bool sum, hipStream_t stream) {
-  if (c->nranks_y == 1) return 0;
-  SMI_REQUIRE(ncomp >= 1 && ncomp <= 3 && d >= 1 && d <= c->g, "y face exchange: bad argument");
-  const int g = c->g, py = c->py;
-  const bool lo = c->rank_y > 0, hi = c->rank_y < c->nranks_y - 1;
-  const size_t bytes = (size_t)ncomp * c->pz * d * c->px * smi_elem_size(c);
-  SMI_REQUIRE(bytes <= c->ybuf_cap, "y face exchange: staging buffer too small");
-  const int src_lo = sum ? 0 : g, src_hi = sum ? py - g : py - g - d;
-  const int dst_lo = sum ? g : g - d, dst_hi = sum ? py - 2 * g : py - g;
-  if (lo) SMI_CHECK((rows_copy<false, false>(c, field, c->ybuf[0], ncomp, d, src_lo, stream)));
-  if (hi) SMI_CHECK((rows_copy<false, false>(c, field, c->ybuf[1], ncomp, d, src_hi, stream)));
-  const int peer_lo = lo ? c->rank - 1 : -1, peer_hi = hi ? c->rank + 1 : -1;
+// d columns of every row of every plane (ghost rows and planes included) of every component <-> a contiguous buffer
+// [comp][z][row][column]
+template <typename T, bool UNPACK, bool ADD>
+__global__ void __launch_bounds__(256) k_cols(T* __restrict__ field, T* __restrict__ buf, int pz, int py, int px, int d,
+                                              int x0, long long plane, long long vol, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int col = (int)(i % d);
+  long long r = i / d;
+  const int row = (int)(r % py);
+  r /= py;
+  const int z = (int)(r % pz), comp = (int)(r / pz);
+  T* cell = field + comp * vol + z * plane + (long long)row * px + x0 + col;
+  if (!UNPACK)
+    buf[i] = *cell;
+  else if (ADD)
+    *cell += buf[i];
+  else
+    *cell = buf[i];
+}
+
+template <bool UNPACK, bool ADD>
+static int cols_copy(smi_ctx* c, void* field, void* buf, int ncomp, int d, int x0, hipStream_t stream) {
+  const long long n = (long long)ncomp * c->pz * c->py * d;
+  SMI_DISPATCH(c, {
+    k_cols<T, UNPACK, ADD><<<(int)((n + 255) / 256), 256, 0, stream>>>((T*)field, (T*)buf, c->pz, c->py, c->px, d, x0,
+                                                                      (long long)c->plane, (long long)c->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// Exchange with the two neighbours along y (AXIS 1: rank -/+ nranks_x) or x (AXIS 2: rank -/+ 1).
+// Halo (sum = false): my first / last d interior rows (columns) -> the neighbour's ghost rows (columns) next to its
+// interior (MPIGhostCommunicator3D, y and x faces).  Ghost sum (sum = true, d = g): my ghost rows (columns) are added
+// to the neighbour's edge interior rows (columns) (MPIGhostSumCommunicator3D.ghost_sum, the y and x steps).
+template <int AXIS>
+static int face_exchange(smi_ctx* c, void* field, int ncomp, int d, bool sum, hipStream_t stream) {
+  const int P = AXIS == 1 ? c->nranks_y : c->nranks_x, me = AXIS == 1 ? c->rank_y : c->rank_x;
+  if (P == 1) return 0;
+  SMI_REQUIRE(ncomp >= 1 && ncomp <= 3 && d >= 1 && d <= c->g, "face exchange: bad argument");
+  const int g = c->g, p = AXIS == 1 ? c->py : c->px, other = AXIS == 1 ? c->px : c->py;
+  const bool lo = me > 0, hi = me < P - 1;
+  const size_t bytes = (size_t)ncomp * c->pz * d * other * smi_elem_size(c);
+  SMI_REQUIRE(bytes <= c->ybuf_cap, "face exchange: staging buffer too small");
+  const int src_lo = sum ? 0 : g, src_hi = sum ? p - g : p - g - d;
+  const int dst_lo = sum ? g : g - d, dst_hi = sum ? p - 2 * g : p - g;
+  auto pack = [&](void* buf, int at) {
+    return AXIS == 1 ? rows_copy<false, false>(c, field, buf, ncomp, d, at, stream)
+                     : cols_copy<false, false>(c, field, buf, ncomp, d, at, stream);
+  };
+  auto unpack = [&](void* buf, int at) {
+    if (sum)
+      return AXIS == 1 ? rows_copy<true, true>(c, field, buf, ncomp, d, at, stream)
+                       : cols_copy<true, true>(c, field, buf, ncomp, d, at, stream);
+    return AXIS == 1 ? rows_copy<true, false>(c, field, buf, ncomp, d, at, stream)
+                     : cols_copy<true, false>(c, field, buf, ncomp, d, at, stream);
+  };
+  if (lo) SMI_CHECK(pack(c->ybuf[0], src_lo));
+  if (hi) SMI_CHECK(pack(c->ybuf[1], src_hi));
+  const int step = AXIS == 1 ? c->nranks_x : 1;
+  const int peer_lo = lo ? c->rank - step : -1, peer_hi = hi ? c->rank + step : -1;
   if (c->sendrecv_cb) {
     SMI_CHECK_HIP(hipStreamSynchronize(stream));
     int rc = c->sendrecv_cb(c->exchange_user, peer_lo, peer_hi, c->ybuf[0], c->ybuf[1], c->ybuf[2], c->ybuf[3], bytes);
-    SMI_REQUIRE(rc == 0, "y face exchange callback failed (%d)", rc);
+    SMI_REQUIRE(rc == 0, "face exchange callback failed (%d)", rc);
   } else {
-    SMI_REQUIRE(c->comm_ready, "y face exchange across ranks needs smi_comm_init or a send-receive callback");
+    SMI_REQUIRE(c->comm_ready, "face exchange across ranks needs smi_comm_init or a send-receive callback");
     SMI_CHECK_NCCL(ncclGroupStart());
     if (lo) {
       SMI_CHECK_NCCL(ncclSend(c->ybuf[0], bytes, ncclChar, peer_lo, c->comm, stream));
@@ -111,14 +157,17 @@ int smi_y_face_exchange(smi_ctx* c, void* field, int ncomp, int d, bool sum, hip
     }
     SMI_CHECK_NCCL(ncclGroupEnd());
   }
-  if (sum) {
-    if (lo) SMI_CHECK((rows_copy<true, true>(c, field, c->ybuf[2], ncomp, d, dst_lo, stream)));
-    if (hi) SMI_CHECK((rows_copy<true, true>(c, field, c->ybuf[3], ncomp, d, dst_hi, stream)));
-  } else {
-    if (lo) SMI_CHECK((rows_copy<true, false>(c, field, c->ybuf[2], ncomp, d, dst_lo, stream)));
-    if (hi) SMI_CHECK((rows_copy<true, false>(c, field, c->ybuf[3], ncomp, d, dst_hi, stream)));
-  }
+  if (lo) SMI_CHECK(unpack(c->ybuf[2], dst_lo));
+  if (hi) SMI_CHECK(unpack(c->ybuf[3], dst_hi));
   return 0;
+}
+
+// y faces, then x faces with the fresh ghost rows in them (the z faces went first): edges and vertices between
+// diagonal neighbours are filled without messages of their own, and the ghost sum cascades z -> y -> x as the
+// reference's does.
+int smi_y_face_exchange(smi_ctx* c, void* field, int ncomp, int d, bool sum, hipStream_t stream) {
+  SMI_CHECK(face_exchange<1>(c, field, ncomp, d, sum, stream));
+  return face_exchange<2>(c, field, ncomp, d, sum, stream);
 }
 
 extern "C" int smi_set_sendrecv_callback(smi_ctx* c, smi_sendrecv_cb cb) {
@@ -161,7 +210,8 @@ int smi_halo_exchange2_on(smi_ctx* c, void* field_a, int ncomp_a, void* field_b,
   SMI_REQUIRE(c->comm_ready, "halo exchange across ranks needs smi_comm_init or an exchange callback");
   const size_t es = smi_elem_size(c);
   const size_t n = (size_t)d * c->plane;  // elements per face per component
-  const int zprev = c->rank - c->nranks_y, znext = c->rank + c->nranks_y;  // the z neighbours of a pencil
+  const int zstep = c->nranks_y * c->nranks_x;  // the z neighbours of a pencil or block
+  const int zprev = c->rank - zstep, znext = c->rank + zstep;
   if (c->nranks_z > 1) {
     SMI_CHECK_NCCL(ncclGroupStart());
     for (int f = 0; f < 2; ++f)
@@ -514,7 +564,8 @@ extern "C" int smi_ghost_sum(smi_ctx* c, void* field, int ncomp) {
     SMI_REQUIRE((size_t)ncomp * n * es <= c->halo_cap, "smi_ghost_sum: staging buffer too small");
     char* base = (char*)field;
     SMI_CHECK_NCCL(ncclGroupStart());
-    const int zprev = c->rank - c->nranks_y, znext = c->rank + c->nranks_y;
+    const int zstep = c->nranks_y * c->nranks_x;
+    const int zprev = c->rank - zstep, znext = c->rank + zstep;
     for (int k = 0; k < ncomp; ++k) {
       char* f = base + (size_t)k * c->vol * es;
       if (c->rank_z > 0) {
@@ -546,12 +597,12 @@ extern "C" int smi_ghost_sum(smi_ctx* c, void* field, int ncomp) {
   return smi_clear_ghost_cells(c, field, ncomp);
 }
 
-// ---------------------------------------------------------------- pencil <-> slab redistribution
-// Rank (rz, ry) of a pencil grid holds planes [rz nzp, (rz + 1) nzp) and rows [ry nyp, (ry + 1) nyp); as rank
-// s = rz Py + ry of the slab decomposition of the same grid it holds planes [s nzs, (s + 1) nzs), nzs = nzp / Py,
-// and every row.  The planes of a pencil are therefore the slabs of the Py ranks of its own row of the rank grid:
-// one all-to-all of equal blocks inside that row moves a field between the two.
-// Block for peer j (pencil -> slab): [comp][nzs planes j nzs ..][nyp][nx], interior cells only.
+// ---------------------------------------------------------------- pencil / block <-> slab redistribution
+// Rank (rz, ry, rx) of a rank grid holds planes [rz nzp, (rz + 1) nzp), rows [ry nyp, ..) and columns [rx nxp, ..); as
+// rank s = (rz Py + ry) Px + rx of the slab decomposition of the same grid it holds planes [s nzs, (s + 1) nzs),
+// nzs = nzp / (Py Px), and every row and column.  The planes of a block are therefore the slabs of the Py Px ranks
+// that share its rz: one all-to-all of equal blocks inside that group moves a field between the two.
+// Block for peer j (block -> slab): [comp][nzs planes j nzs ..][nyp][nxp], interior cells only.
 template <typename T, bool TO_WORK>
 __global__ void __launch_bounds__(256) k_pencil_blocks(T* __restrict__ work, T* __restrict__ pencil, int ncomp, int nzs,
                                                        int nyp, int nx, int g, int px, long long plane, long long vol,
@@ -571,21 +622,22 @@ __global__ void __launch_bounds__(256) k_pencil_blocks(T* __restrict__ work, T* 
   else
     *cell = work[i];
 }
-// Block from peer j (in the slab): [comp][nzs][nyp rows j nyp ..][nx]
+// Block from peer j = jy Px + jx (in the slab): [comp][nzs][nyp rows jy nyp ..][nxp columns jx nxp ..]
 template <typename T, bool TO_WORK>
 __global__ void __launch_bounds__(256) k_slab_blocks(T* __restrict__ work, T* __restrict__ slab, int ncomp, int nzs,
-                                                     int nyp, int nx, int g, int px, long long plane, long long vol,
-                                                     long long n) {
+                                                     int nyp, int nxp, int Px, int g, int px, long long plane,
+                                                     long long vol, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int x = (int)(i % nx);
-  long long r = i / nx;
+  const int x = (int)(i % nxp);
+  long long r = i / nxp;
   const int y = (int)(r % nyp);
   r /= nyp;
   const int z = (int)(r % nzs);
   r /= nzs;
   const int comp = (int)(r % ncomp), j = (int)(r / ncomp);
-  T* cell = slab + comp * vol + (long long)(g + z) * plane + (long long)(g + j * nyp + y) * px + g + x;
+  const int jy = j / Px, jx = j - jy * Px;
+  T* cell = slab + comp * vol + (long long)(g + z) * plane + (long long)(g + jy * nyp + y) * px + g + jx * nxp + x;
   if (TO_WORK)
     work[i] = *cell;
   else
@@ -621,12 +673,47 @@ static int group_alltoall(smi_ctx* c, const void* send, void* recv, size_t bytes
 
 static int redistribution_shapes(const smi_ctx* p, const smi_ctx* s, int ncomp, const char* who) {
   SMI_REQUIRE(p && s && ncomp >= 1 && ncomp <= 3, "%s: bad argument", who);
-  SMI_REQUIRE(p->dtype == s->dtype && p->g == s->g && p->nx == s->nx && p->rank == s->rank && p->nranks == s->nranks &&
-                  s->nranks_y == 1,
+  SMI_REQUIRE(p->dtype == s->dtype && p->g == s->g && p->rank == s->rank && p->nranks == s->nranks &&
+                  s->nranks_y == 1 && s->nranks_x == 1,
               "%s: the two contexts do not describe the same rank, precision and ghost size", who);
-  SMI_REQUIRE(p->nz % p->nranks_y == 0 && s->nz == p->nz / p->nranks_y && s->ny == p->ny * p->nranks_y,
-              "%s: a pencil of %d x %d does not split into slabs of %d x %d over %d ranks", who, p->nz, p->ny, s->nz,
-              s->ny, p->nranks_y);
+  const int group = p->nranks_y * p->nranks_x;
+  SMI_REQUIRE(p->nz % group == 0 && s->nz == p->nz / group && s->ny == p->ny * p->nranks_y &&
+                  s->nx == p->nx * p->nranks_x,
+              "%s: a block of %d x %d x %d does not split into slabs of %d x %d x %d over %d ranks", who, p->nz, p->ny,
+              p->nx, s->nz, s->ny, s->nx, group);
+  return 0;
+}
+
+template <bool TO_SLAB>
+static int redistribute(smi_ctx* p, smi_ctx* sl, void* slab_field, void* pencil_field, int ncomp, void* work_a,
+                        void* work_b) {
+  smi_ctx* c = p;
+  const int group = p->nranks_y * p->nranks_x, nzs = sl->nz, nyp = p->ny, nxp = p->nx;
+  const long long n = (long long)group * ncomp * nzs * nyp * nxp;
+  const size_t per_peer = (size_t)ncomp * nzs * nyp * nxp * smi_elem_size(p);
+  const int blocks = (int)((n + 255) / 256);
+  // both copies run on the pencil context's stream: the caller orders the slab context's work around them
+  SMI_DISPATCH(c, {
+    if (TO_SLAB)
+      k_pencil_blocks<T, true><<<blocks, 256, 0, p->stream>>>((T*)work_a, (T*)pencil_field, ncomp, nzs, nyp, nxp, p->g,
+                                                             p->px, (long long)p->plane, (long long)p->vol, n);
+    else
+      k_slab_blocks<T, true><<<blocks, 256, 0, p->stream>>>((T*)work_a, (T*)slab_field, ncomp, nzs, nyp, nxp,
+                                                           p->nranks_x, sl->g, sl->px, (long long)sl->plane,
+                                                           (long long)sl->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
+  SMI_CHECK(group_alltoall(p, work_a, work_b, per_peer, p->rank_z * group, group));
+  SMI_DISPATCH(c, {
+    if (TO_SLAB)
+      k_slab_blocks<T, false><<<blocks, 256, 0, p->stream>>>((T*)work_b, (T*)slab_field, ncomp, nzs, nyp, nxp,
+                                                            p->nranks_x, sl->g, sl->px, (long long)sl->plane,
+                                                            (long long)sl->vol, n);
+    else
+      k_pencil_blocks<T, false><<<blocks, 256, 0, p->stream>>>((T*)work_b, (T*)pencil_field, ncomp, nzs, nyp, nxp, p->g,
+                                                              p->px, (long long)p->plane, (long long)p->vol, n);
+  });
+  SMI_LAUNCH_CHECK();
   return 0;
 }
 
@@ -634,47 +721,12 @@ extern "C" int smi_pencil_to_slab(smi_ctx* p, smi_ctx* sl, void* slab_field, con
                                   void* work_a, void* work_b) {
   SMI_CHECK(redistribution_shapes(p, sl, ncomp, "smi_pencil_to_slab"));
   SMI_REQUIRE(slab_field && pencil_field && work_a && work_b, "smi_pencil_to_slab: null array");
-  smi_ctx* c = p;
-  const int Py = p->nranks_y, nzs = sl->nz, nyp = p->ny, nx = p->nx;
-  const long long n = (long long)Py * ncomp * nzs * nyp * nx;
-  const size_t per_peer = (size_t)ncomp * nzs * nyp * nx * smi_elem_size(p);
-  SMI_DISPATCH(c, {
-    k_pencil_blocks<T, true><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_a, (T*)pencil_field, ncomp, nzs, nyp,
-                                                                            nx, p->g, p->px, (long long)p->plane,
-                                                                            (long long)p->vol, n);
-  });
-  SMI_LAUNCH_CHECK();
-  SMI_CHECK(group_alltoall(p, work_a, work_b, per_peer, p->rank_z * Py, Py));
-  // the unpack runs on the pencil context's stream too: the caller orders the slab context's work behind it
-  SMI_DISPATCH(c, {
-    k_slab_blocks<T, false><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_b, (T*)slab_field, ncomp, nzs, nyp, nx,
-                                                                           sl->g, sl->px, (long long)sl->plane,
-                                                                           (long long)sl->vol, n);
-  });
-  SMI_LAUNCH_CHECK();
-  return 0;
+  return redistribute<true>(p, sl, slab_field, (void*)pencil_field, ncomp, work_a, work_b);
 }
 
 extern "C" int smi_slab_to_pencil(smi_ctx* p, smi_ctx* sl, void* pencil_field, const void* slab_field, int ncomp,
                                   void* work_a, void* work_b) {
   SMI_CHECK(redistribution_shapes(p, sl, ncomp, "smi_slab_to_pencil"));
   SMI_REQUIRE(slab_field && pencil_field && work_a && work_b, "smi_slab_to_pencil: null array");
-  smi_ctx* c = p;
-  const int Py = p->nranks_y, nzs = sl->nz, nyp = p->ny, nx = p->nx;
-  const long long n = (long long)Py * ncomp * nzs * nyp * nx;
-  const size_t per_peer = (size_t)ncomp * nzs * nyp * nx * smi_elem_size(p);
-  SMI_DISPATCH(c, {
-    k_slab_blocks<T, true><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_a, (T*)slab_field, ncomp, nzs, nyp, nx,
-                                                                          sl->g, sl->px, (long long)sl->plane,
-                                                                          (long long)sl->vol, n);
-  });
-  SMI_LAUNCH_CHECK();
-  SMI_CHECK(group_alltoall(p, work_a, work_b, per_peer, p->rank_z * Py, Py));
-  SMI_DISPATCH(c, {
-    k_pencil_blocks<T, false><<<(int)((n + 255) / 256), 256, 0, p->stream>>>((T*)work_b, (T*)pencil_field, ncomp, nzs, nyp,
-                                                                             nx, p->g, p->px, (long long)p->plane,
-                                                                             (long long)p->vol, n);
-  });
-  SMI_LAUNCH_CHECK();
-  return 0;
+  return redistribute<false>(p, sl, (void*)slab_field, pencil_field, ncomp, work_a, work_b);
 }

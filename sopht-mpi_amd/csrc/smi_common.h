@@ -26,6 +26,11 @@ struct smi_ctx {
   // z-slabs are nranks_y = 1.
   int rank_z, nranks_z, rank_y, nranks_y;
   int phys_ylo, phys_yhi;
+  // smi_ctx_set_grid3: x divided as well, rank = (rank_z * nranks_y + rank_y) * nranks_x + rank_x.  The stencil
+  // operators, the exchanges and the immersed-boundary kernels serve it; the transforms do not (a Poisson solve is
+  // routed through the z-slab decomposition, the one-pass kernels fall back where rows are no whole vectors).
+  int rank_x, nranks_x;
+  int phys_xlo, phys_xhi;
   // y faces are strided in memory: they are packed into / unpacked from these device buffers
   // ([0] to the previous y rank, [1] to the next, [2] from the previous, [3] from the next; 3 components of g rows
   // of every plane each), allocated by smi_ctx_set_pencil

@@ -94,6 +94,9 @@ static int ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int 
   c->rank_y = 0;
   c->nranks_y = 1;
   c->phys_ylo = c->phys_yhi = 1;
+  c->rank_x = 0;
+  c->nranks_x = 1;
+  c->phys_xlo = c->phys_xhi = 1;
   if (nz == 1 && nranks > 1) {
     // 2D: the ranks divide the rows (mpi_utils_2d.py:9-84 with the default rank_distribution)
     c->rank_z = 0;
@@ -169,29 +172,41 @@ extern "C" int smi_ctx_get_option(smi_ctx* c, const char* name, int* value) {
   return 0;
 }
 
-extern "C" int smi_ctx_set_pencil(smi_ctx* c, int rank_z, int nranks_z, int rank_y, int nranks_y) {
-  SMI_REQUIRE(c, "smi_ctx_set_pencil: null context");
-  SMI_REQUIRE(nranks_z >= 1 && nranks_y >= 1 && nranks_z * nranks_y == c->nranks,
-              "smi_ctx_set_pencil: a %d x %d rank grid does not hold the %d ranks of this context", nranks_z, nranks_y,
-              c->nranks);
-  SMI_REQUIRE(rank_z >= 0 && rank_z < nranks_z && rank_y >= 0 && rank_y < nranks_y &&
-                  rank_z * nranks_y + rank_y == c->rank,
-              "smi_ctx_set_pencil: position (%d, %d) is not rank %d of a %d x %d grid", rank_z, rank_y, c->rank,
-              nranks_z, nranks_y);
+extern "C" int smi_ctx_set_grid3(smi_ctx* c, int rank_z, int nranks_z, int rank_y, int nranks_y, int rank_x,
+                                 int nranks_x) {
+  SMI_REQUIRE(c, "smi_ctx_set_grid3: null context");
+  SMI_REQUIRE(nranks_z >= 1 && nranks_y >= 1 && nranks_x >= 1 && nranks_z * nranks_y * nranks_x == c->nranks,
+              "smi_ctx_set_grid3: a %d x %d x %d rank grid does not hold the %d ranks of this context", nranks_z,
+              nranks_y, nranks_x, c->nranks);
+  SMI_REQUIRE(rank_z >= 0 && rank_z < nranks_z && rank_y >= 0 && rank_y < nranks_y && rank_x >= 0 && rank_x < nranks_x &&
+                  (rank_z * nranks_y + rank_y) * nranks_x + rank_x == c->rank,
+              "smi_ctx_set_grid3: position (%d, %d, %d) is not rank %d of a %d x %d x %d grid", rank_z, rank_y, rank_x,
+              c->rank, nranks_z, nranks_y, nranks_x);
+  SMI_REQUIRE(c->nz > 1 || nranks_x == 1, "smi_ctx_set_grid3: the 2D operators divide rows only");
   c->rank_z = rank_z;
   c->nranks_z = nranks_z;
   c->rank_y = rank_y;
   c->nranks_y = nranks_y;
+  c->rank_x = rank_x;
+  c->nranks_x = nranks_x;
   c->phys_zlo = rank_z == 0;
   c->phys_zhi = rank_z == nranks_z - 1;
   c->phys_ylo = rank_y == 0;
   c->phys_yhi = rank_y == nranks_y - 1;
-  if (nranks_y > 1 && !c->ybuf[0]) {
+  c->phys_xlo = rank_x == 0;
+  c->phys_xhi = rank_x == nranks_x - 1;
+  if ((nranks_y > 1 || nranks_x > 1) && !c->ybuf[0]) {
+    // packed y or x faces: 3 components of g rows (columns) of every plane
     SMI_CHECK_HIP(hipSetDevice(c->device));
-    c->ybuf_cap = (size_t)3 * c->pz * c->g * c->px * smi_elem_size(c);
+    c->ybuf_cap = (size_t)3 * c->pz * c->g * (c->px > c->py ? c->px : c->py) * smi_elem_size(c);
     for (int i = 0; i < 4; ++i) SMI_CHECK_HIP(hipMalloc(&c->ybuf[i], c->ybuf_cap));
   }
   return 0;
+}
+
+extern "C" int smi_ctx_set_pencil(smi_ctx* c, int rank_z, int nranks_z, int rank_y, int nranks_y) {
+  SMI_REQUIRE(c, "smi_ctx_set_pencil: null context");
+  return smi_ctx_set_grid3(c, rank_z, nranks_z, rank_y, nranks_y, 0, 1);
 }
 
 extern "C" int smi_ctx_destroy(smi_ctx* c) {

@@ -112,7 +112,8 @@ extern "C" int smi_fft_create(smi_fft** out, smi_ctx* c, int nz, int ny, int nx)
   SMI_REQUIRE(out && c, "smi_fft_create: null argument");
   SMI_REQUIRE(nz >= 1 && ny >= 2 && nx >= 2, "smi_fft_create: bad grid (%d, %d, %d)", nz, ny, nx);
   const int P = c->nranks;
-  SMI_REQUIRE(P == 1 || (nz > 1 && c->nranks_y == 1), "smi_fft_create: several ranks divide a 3D transform into z-slabs");
+  SMI_REQUIRE(P == 1 || (nz > 1 && c->nranks_y == 1 && c->nranks_x == 1),
+              "smi_fft_create: several ranks divide a 3D transform into z-slabs");
   SMI_REQUIRE(nz % P == 0 && ny % P == 0,
               "smi_fft_create: %d ranks must divide nz = %d (real array) and ny = %d (spectrum)", P, nz, ny);
   SMI_CHECK_HIP(hipSetDevice(c->device));
@@ -290,7 +291,7 @@ static int doubled_stage(smi_ctx* c, size_t bytes) {
 template <bool TO_DOUBLED>
 static int doubled_copy_slabs(smi_ctx* c, void* local_field, void* local_doubled_field) {
   const int P = c->nranks, r = c->rank;
-  SMI_REQUIRE(c->nranks_y == 1 && c->nz > 1 && P % 2 == 0,
+  SMI_REQUIRE(c->nranks_y == 1 && c->nranks_x == 1 && c->nz > 1 && P % 2 == 0,
               "the doubled-domain copies across ranks serve an even number of z-slabs (got %d ranks)", P);
   const long long n = (long long)c->nz * c->ny * c->nx;
   const size_t bytes = (size_t)n * smi_elem_size(c);

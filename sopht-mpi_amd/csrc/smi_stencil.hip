@@ -26,6 +26,7 @@ struct Geo {
   long long plane, vol;
   int zlo_c, zhi_c;  // inclusive z range of the zero-banded compute set D
   int ylo_c, yhi_c;  // the same in y (differs from [g + 1, py - g - 2] only on the inner faces of a pencil)
+  int xlo_c, xhi_c;  // and in x (inner faces of a rank grid that divides x)
   // z range over which the one-pass advection + diffusion kernel forms the advected vorticity on the core cells:
   // the planes the vorticity update writes there, [g, pz - g - 1], plus the ghost plane next to a neighbouring
   // rank (what that rank computes for its own edge plane, needed by the diffusion stencil of this rank's edge)
@@ -33,6 +34,7 @@ struct Geo {
   // the same across an inner y face of a pencil: the ghost row there is the neighbour's FACE row (on_face in its
   // frame), so the one-pass kernel applies the face part of the update set to it; -1 next to a physical face
   int yf_lo, yf_hi;
+  int xf_lo, xf_hi;  // likewise the ghost column across an inner x face
 };
 
 Geo make_geo(const smi_ctx* c) {
@@ -53,6 +55,10 @@ Geo make_geo(const smi_ctx* c) {
   G.za_hi = c->pz - c->g - 1 + (c->phys_zhi ? 0 : 1);
   G.yf_lo = c->phys_ylo ? -1 : c->g - 1;
   G.yf_hi = c->phys_yhi ? -1 : c->py - c->g;
+  G.xlo_c = c->g + (c->phys_xlo ? 1 : 0);
+  G.xhi_c = c->px - c->g - 1 - (c->phys_xhi ? 1 : 0);
+  G.xf_lo = c->phys_xlo ? -1 : c->g - 1;
+  G.xf_hi = c->phys_xhi ? -1 : c->px - c->g;
   return G;
 }
 
@@ -154,6 +160,7 @@ __device__ __forceinline__ bool lane_pos(const Geo& G, const Blk& B, long long& 
 __device__ __forceinline__ bool in_core(int a, int p, int g) { return a >= g + 1 && a <= p - g - 2; }
 // rows of the zero-banded compute set D (in_core(y) unless a y face of this rank borders another rank)
 __device__ __forceinline__ bool in_core_y(const Geo& G, int y) { return y >= G.ylo_c && y <= G.yhi_c; }
+__device__ __forceinline__ bool in_core_x(const Geo& G, int x) { return x >= G.xlo_c && x <= G.xhi_c; }
 __device__ __forceinline__ bool on_face(int a, int p, int g) { return a == g || a == p - g - 1; }
 __device__ __forceinline__ bool in_ext(int a, int p) { return a >= 1 && a <= p - 2; }
 
@@ -174,7 +181,7 @@ __global__ void __launch_bounds__(kBlock) k_diffusion_flux(T* __restrict__ flux,
   bool ycore = in_core_y(G, y);
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    core[e] = ycore && in_core(x0 + e, G.px, G.g);
+    core[e] = ycore && in_core_x(G, x0 + e);
     any |= core[e];
   }
   int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(kBlock) k_curl(T* out, const T* __restrict__ f
   const bool yc = MODE == 0 ? in_core_y(G, y) : in_core(y, G.py, G.g), yf = on_face(y, G.py, G.g), ye = in_ext(y, G.py);
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
+    bool xc = MODE == 0 ? in_core_x(G, x0 + e) : in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
     mA[e] = yc && xc;
     mB[e] = MODE != 0 && ((yf && xc) || (ye && xf));
     any |= mA[e] || mB[e];
@@ -704,8 +711,9 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
     const bool yf = on_face(y, G.py, G.g) || y == G.yf_lo || y == G.yf_hi;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const bool xc = in_core(x0 + e, G.px, G.g), xf = on_face(x0 + e, G.px, G.g);
-      mA |= ((unsigned)(yc && xc) << e) | ((unsigned)(yd && xc) << (8 + e));
+      const bool xc = in_core(x0 + e, G.px, G.g), xd = in_core_x(G, x0 + e);
+      const bool xf = on_face(x0 + e, G.px, G.g) || x0 + e == G.xf_lo || x0 + e == G.xf_hi;
+      mA |= ((unsigned)(yc && xc) << e) | ((unsigned)(yd && xd) << (8 + e));
       mB |= (unsigned)((yf && xc) || (ye && xf)) << e;
     }
   }
@@ -897,7 +905,7 @@ __global__ void __launch_bounds__(kTileThreads) k_diffuse_tiled(T* __restrict__ 
   {
     const bool yc = L.own && in_core_y(G, L.y);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) core[e] = yc && in_core(L.x0 + e, G.px, G.g);
+    for (int e = 0; e < 4; ++e) core[e] = yc && in_core_x(G, L.x0 + e);
   }
   const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
   const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
@@ -983,7 +991,7 @@ __global__ void __launch_bounds__(kTileThreads) k_curl_tiled(T* __restrict__ out
   {
     const bool yc = L.own && in_core_y(G, L.y);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) core[e] = yc && in_core(L.x0 + e, G.px, G.g);
+    for (int e = 0; e < 4; ++e) core[e] = yc && in_core_x(G, L.x0 + e);
   }
   // chunk of this workgroup: chunk0 + chunk_step * (position along grid y), as in k_advect_diffuse
   const int z0 = (chunk0 + chunk_step * B.y) * zchunk, z1 = min(z0 + zchunk, G.pz);
@@ -1162,7 +1170,7 @@ __global__ void __launch_bounds__(kBlock) k_divergence(T* __restrict__ div, cons
   int z = (int)(i / G.plane);
   long long r = i - (long long)z * G.plane;
   int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
-  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core_y(G, y) && in_core(x, G.px, G.g);
+  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core_y(G, y) && in_core_x(G, x);
   T v = T(0);
   if (ok) {
     const T* fx = f + i;
@@ -1183,7 +1191,7 @@ __global__ void __launch_bounds__(kBlock) k_filter_pass(T* __restrict__ flux, co
   int z = (int)(i / G.plane);
   long long r = i - (long long)z * G.plane;
   int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
-  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core_y(G, y) && in_core(x, G.px, G.g);
+  bool ok = z >= G.zlo_c && z <= G.zhi_c && in_core_y(G, y) && in_core_x(G, x);
   T v = T(0);
   if (ok) {
     const long long d = AXIS == 0 ? 1 : (AXIS == 1 ? (long long)G.px : G.plane);
@@ -1211,7 +1219,7 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
   bool xc[V], anyx = false;
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    xc[e] = in_core(x0 + e, G.px, G.g);
+    xc[e] = in_core_x(G, x0 + e);
     anyx |= xc[e];
   }
   // rows of D, and the rows whose Lx the y pass may read: D plus the ghost row across an inner y face of a pencil
@@ -1268,14 +1276,14 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
 // zero the outer (g + width) layers next to physical faces (zero_bands of the wrappers)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_zero_bands(T* __restrict__ f, Geo G, int w, int zlo, int zhi, int ylo,
-                                                      int yhi) {
+                                                      int yhi, int xlo = 1, int xhi = 1) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G.vol) return;
   int z = (int)(i / G.plane);
   long long r = i - (long long)z * G.plane;
   int y = (int)(r / G.px), x = (int)(r - (long long)y * G.px);
-  bool band = x < w || x >= G.px - w || (ylo && y < w) || (yhi && y >= G.py - w) || (zlo && z < w) ||
-              (zhi && z >= G.pz - w);
+  bool band = (xlo && x < w) || (xhi && x >= G.px - w) || (ylo && y < w) || (yhi && y >= G.py - w) ||
+              (zlo && z < w) || (zhi && z >= G.pz - w);
   if (band) f[i] = T(0);
 }
 
@@ -1452,7 +1460,7 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
     nchunks = (int)tl.grid.y;
     while (n_lo < nchunks && n_lo * tl.zchunk < c->g + 1) ++n_lo;
     while (n_hi < nchunks - n_lo && (nchunks - n_hi) * tl.zchunk > c->pz - c->g - 1) ++n_hi;
-    overlap = smi_multi_rank(c) && !c->exchange_cb && c->nranks_y == 1 && nchunks - n_lo - n_hi >= 1;
+    overlap = smi_multi_rank(c) && !c->exchange_cb && c->nranks_y == 1 && c->nranks_x == 1 && nchunks - n_lo - n_hi >= 1;
   }
   if (smi_multi_rank(c)) {
     if (overlap) {
@@ -1782,7 +1790,7 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   // them are at least g + 2 planes long (the last one is the remainder of the division)
   const int last_chunk = c->pz - (nchunks - 1) * zchunk;
   // (the ghost rows of a pencil's y faces reach every chunk: no overlap there)
-  const bool overlap = !c->exchange_cb && c->nranks_y == 1 && nchunks >= 3 && zchunk >= c->g + 2 && last_chunk >= c->g + 2;
+  const bool overlap = !c->exchange_cb && c->nranks_y == 1 && c->nranks_x == 1 && nchunks >= 3 && zchunk >= c->g + 2 && last_chunk >= c->g + 2;
   auto exchange = [&]() -> int {
     if (!overlap) return smi_halo_exchange2_impl(c, velocity, 3, vorticity, 3);
     // No RCCL call may be issued on c->stream while this exchange is pending on the communication stream (one
@@ -1867,8 +1875,9 @@ extern "C" int smi_penalise_boundary(smi_ctx* c, void* field, int ncomp, int wid
   Geo G = make_geo(c);
   SmiProfScope prof(c, PROF_PENALISE, 0.0);
   SMI_DISPATCH(c, {
-    k_penalise<T, 0><<<blocks_for((long long)G.pz * G.py * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
-                                                                                         fac, 1, 1);
+    if (c->phys_xlo || c->phys_xhi)
+      k_penalise<T, 0><<<blocks_for((long long)G.pz * G.py * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
+                                                                                           fac, c->phys_xlo, c->phys_xhi);
     if (c->phys_ylo || c->phys_yhi)
       k_penalise<T, 1><<<blocks_for((long long)G.pz * G.px * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
                                                                                            fac, c->phys_ylo, c->phys_yhi);
@@ -1937,6 +1946,8 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
   G.zhi_c = c->pz - c->g - 1 - (c->phys_zhi ? w : 0);
   G.ylo_c = c->g + (c->phys_ylo ? w : 0);
   G.yhi_c = c->py - c->g - 1 - (c->phys_yhi ? w : 0);
+  G.xlo_c = c->g + (c->phys_xlo ? w : 0);
+  G.xhi_c = c->px - c->g - 1 - (c->phys_xhi ? w : 0);
   if (filter_type == SMI_FILTER_MULTIPLICATIVE && order == 1 && w == 1) {
     // one fused pass into the scratch field, then back (the scratch fields hold one component)
     const size_t stride = c->vol * smi_elem_size(c);
@@ -1960,7 +1971,7 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
         if (order == 0) {
           // degenerate: field -= (stale flux buffer with its physical bands cleared)
           k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi,
-                                                                       c->phys_ylo, c->phys_yhi);
+                                                                       c->phys_ylo, c->phys_yhi, c->phys_xlo, c->phys_xhi);
           SMI_LAUNCH_CHECK();
           SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
           continue;
@@ -1978,7 +1989,8 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
         for (int axis = 0; axis < 3; ++axis) {
           if (order == 0) {
             k_zero_bands<T><<<blocks_for(G.vol), kBlock, 0, c->stream>>>(flux, G, c->g + w, c->phys_zlo, c->phys_zhi,
-                                                                       c->phys_ylo, c->phys_yhi);
+                                                                       c->phys_ylo, c->phys_yhi, c->phys_xlo,
+                                                                       c->phys_xhi);
             SMI_LAUNCH_CHECK();
             SMI_CHECK(smi_elementwise_saxpby(c, f, f, 1.0, flux, -1.0, 1));
             continue;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "smi_update_vorticity_from_penalised_velocity": [_p, _p, _p, _p, _d],
     "smi_brinkmann_penalise": [_p, _p, _p, _p, _p, _d, _i],
     "smi_char_func_from_level_set": [_p, _p, _p, _d],
+    "smi_ctx_set_grid3": [_p, _i, _i, _i, _i, _i, _i],
     "smi_ctx_set_block": [_p, _p, _p, _p],
     "smi_ctx_create_block": [_pp, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "smi_halo_exchange_general": [_p, _p, _i, _i],

@@ -61,10 +61,13 @@ class DeviceContext:
         self.block = block
         if block is not None:
             rank_grid = None
-        self.rank_grid = (self.nranks, 1) if rank_grid is None else (int(rank_grid[0]), int(rank_grid[1]))
-        self.rank_z, self.rank_y = divmod(self.rank, self.rank_grid[1])
-        if self.rank_grid[1] > 1:
-            call("smi_ctx_set_pencil", h, self.rank_z, self.rank_grid[0], self.rank_y, self.rank_grid[1])
+        grid = (self.nranks, 1, 1) if rank_grid is None else tuple(int(v) for v in rank_grid)
+        self.rank_grid = grid if len(grid) == 3 else grid + (1,)
+        self.rank_z, rest = divmod(self.rank, self.rank_grid[1] * self.rank_grid[2])
+        self.rank_y, self.rank_x = divmod(rest, self.rank_grid[2])
+        if self.rank_grid[1] > 1 or self.rank_grid[2] > 1:
+            call("smi_ctx_set_grid3", h, self.rank_z, self.rank_grid[0], self.rank_y, self.rank_grid[1], self.rank_x,
+                 self.rank_grid[2])
         self.padded_shape = tuple(n + 2 * self.ghost_size for n in self.local_grid_size)
         self.transport = "none" if nranks == 1 else None
         self._cb = None
@@ -92,9 +95,9 @@ class DeviceContext:
         """Host-staged plane transport through the world's point-to-point (ranks sharing a GPU)."""
         g, pz = self.ghost_size, self.padded_shape[0]
         plane = self.padded_shape[1] * self.padded_shape[2]
-        ranks_y = self.rank_grid[1]
-        prev = self.rank - ranks_y if self.rank_z > 0 else None                    # the z neighbours
-        nxt = self.rank + ranks_y if self.rank_z < self.rank_grid[0] - 1 else None
+        plane_of_ranks = self.rank_grid[1] * self.rank_grid[2]
+        prev = self.rank - plane_of_ranks if self.rank_z > 0 else None             # the z neighbours
+        nxt = self.rank + plane_of_ranks if self.rank_z < self.rank_grid[0] - 1 else None
         dt = np.dtype(self.real_t)
 
         def exchange(_user, field, ncomp, kind):

@@ -329,7 +329,7 @@ class UnboundedPoissonSolverMPI3D:
         # smi_pencil_to_slab / smi_slab_to_pencil), the way the reference's solver moves its fields between the
         # grid's and the doubled domain's decomposition (UnboundedPoissonSolverMPI3D.py:190-382).
         self.pencil_ctx = None
-        if mpi_construct.size > 1 and mpi_construct.grid_topology[1] > 1:
+        if mpi_construct.size > 1 and (mpi_construct.grid_topology[1] > 1 or mpi_construct.grid_topology[2] > 1):
             self.pencil_ctx = self.ctx
             self.ctx = mpi_construct.slab_context(ghost_size)
             block = int(np.prod(self.pencil_ctx.local_grid_size))

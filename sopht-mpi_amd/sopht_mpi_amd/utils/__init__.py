@@ -129,9 +129,9 @@ class MPIConstruct3D:
             rank_distribution = [0, 1, 1] if self.size > 1 else [0, 0, 1]
         self.rank_distribution = list(rank_distribution)
         self.grid_topology = compute_dims(self.size, self.rank_distribution) if self.size > 1 else [1, 1, 1]
-        # a divided x axis or a periodic domain: topology and communicators only (the reference's own tests of those
-        # classes run on such decompositions, tests/test_utils/test_mpi_utils_3d.py:95-125)
-        self.general_topology = self.periodic_domain or self.grid_topology[2] > 1
+        # a periodic domain: topology and communicators only (the reference's own test of the ghost communicator runs
+        # on one, tests/test_utils/test_mpi_utils_3d.py:95-125)
+        self.general_topology = self.periodic_domain
         self.global_grid_size = np.array((grid_size_z, grid_size_y, grid_size_x))
         if np.any(self.global_grid_size % self.grid_topology):
             logger.error("Cannot divide grid evenly to processors in x, y and/or z directions!")
@@ -159,7 +159,7 @@ class MPIConstruct3D:
                 block = (tuple(int(v) for v in self.grid.coords), tuple(int(t) for t in self.grid_topology),
                          (self.periodic_domain,) * 3)
             ctx = DeviceContext(self.local_grid_size, ghost_size, self.real_t, rank=self.rank, nranks=self.size,
-                                world=self.world, rank_grid=(self.grid_topology[0], self.grid_topology[1]), block=block)
+                                world=self.world, rank_grid=tuple(int(t) for t in self.grid_topology), block=block)
             self._start_transport(ctx)
             self._contexts[ghost_size] = ctx
         return ctx

@@ -52,7 +52,9 @@ for dist, aspect, periodic, real_t, ghost, full in itertools.product(
     if construct is None:
         continue
     topo = tuple(int(t) for t in construct.grid_topology)
-    general = periodic or topo[-1] > 1
+    # 3D: the operators' own contexts serve a divided x axis; periodic domains (and, in 2D, divided columns) go
+    # through the general block exchange
+    general = periodic or (dim == 2 and topo[-1] > 1)
     assert construct.general_topology == general
     local = tuple(int(v) for v in construct.local_grid_size)
     coords = tuple(int(v) for v in construct.grid.coords)

@@ -38,18 +38,21 @@ kw = dict(grid_size=n, x_range=1.0, kinematic_viscosity=1e-2, flow_type=flow_typ
 if with_filter:
     kw["filter_setting_dict"] = {"order": 1, "type": "multiplicative"}
 # "pencil": the reference's default decomposition over z and y (utils/mpi_utils_3d.py:32-48); "yslab": slabs along y
-rank_distribution = (0, 0, 1) if "pencil" in sys.argv[4:] else ((1, 0, 1) if "yslab" in sys.argv[4:] else None)
+# "xslab" / "yx" / "zx": the decompositions of the reference's operator tests that divide x - (1, 1, 0), (1, 0, 0),
+# (0, 1, 0) (tests/test_numeric/test_eulerian_grid_ops/test_stencil_ops_3d/test_diffusion_flux_mpi_3d.py:20-23)
+_named = {"pencil": (0, 0, 1), "yslab": (1, 0, 1), "xslab": (1, 1, 0), "yx": (1, 0, 0), "zx": (0, 1, 0)}
+rank_distribution = next((d for name, d in _named.items() if name in sys.argv[4:]), None)
 gpu = UnboundedFlowSimulator3D(fused_step=fused, rank_distribution=rank_distribution, **kw)
 assert gpu.unbounded_poisson_solver.backend == "pruned"
 topo = gpu.mpi_construct.grid_topology
-assert int(np.prod(topo)) == size and topo[2] == 1
+assert int(np.prod(topo)) == size
 if rank_distribution is None:
     assert list(topo) == [size, 1, 1]
 elif rank_distribution == (0, 0, 1):
     assert topo[1] > 1 or size < 4, topo
 else:
-    assert list(topo) == [1, size, 1]
-assert list(gpu.mpi_construct.local_grid_size) == [n[0] // topo[0], n[1] // topo[1], n[2]]
+    assert all(t == 1 for t, aligned in zip(topo, rank_distribution) if aligned), topo
+assert list(gpu.mpi_construct.local_grid_size) == [n[0] // topo[0], n[1] // topo[1], n[2] // topo[2]]
 g = gpu.ghost_size
 comm = MPIFieldCommunicator3D(g, gpu.mpi_construct)
 rng = np.random.default_rng(7)

@@ -70,20 +70,21 @@ def test_topology_and_errors(smi):
     # nothing aligned: MPI.Compute_dims spreads 4 ranks as 2 x 2 x 1, which leaves x whole
     f4 = MPIConstruct3D(16, 8, 8, rank_distribution=(0, 0, 0), world=FakeWorld())
     assert list(f4.grid_topology) == [2, 2, 1] and not f4.general_topology
-    # a divided x axis and a periodic domain (what the reference's own communicator tests run on,
-    # tests/test_utils/test_mpi_utils_3d.py:95-125): the topology is served, the operators are not
+    # a divided x axis (the reference's operator tests run on (1, 1, 0), (1, 0, 0) and (0, 1, 0) too)
     x4 = MPIConstruct3D(16, 8, 8, rank_distribution=(1, 1, 0), world=FakeWorld())
-    assert list(x4.grid_topology) == [1, 1, 4] and list(x4.local_grid_size) == [16, 8, 2] and x4.general_topology
+    assert list(x4.grid_topology) == [1, 1, 4] and list(x4.local_grid_size) == [16, 8, 2] and not x4.general_topology
     assert list(x4.grid.coords) == [0, 0, 1]
     assert list(x4.previous_grid_along) == [PROC_NULL, PROC_NULL, 0] and list(x4.next_grid_along) == [PROC_NULL, PROC_NULL, 2]
-    with pytest.raises(NotImplementedError):
-        x4.device_context(2)
-    with pytest.raises(NotImplementedError):
-        x4.slab_context(2)
+    # a periodic domain (what the reference's own ghost communicator test runs on,
+    # tests/test_utils/test_mpi_utils_3d.py:95-125): the topology and the communicators are served, the operators not
     per = MPIConstruct3D(16, 8, 8, periodic_domain=True, rank_distribution=(0, 0, 1), world=FakeWorld())
     assert per.general_topology and list(per.grid_topology) == [2, 2, 1] and list(per.grid.coords) == [0, 1, 0]
     # Cart_shift on periodic axes wraps; an axis with one rank wraps onto the rank itself
     assert list(per.previous_grid_along) == [3, 0, 1] and list(per.next_grid_along) == [3, 0, 1]
+    with pytest.raises(NotImplementedError):
+        per.device_context(2)
+    with pytest.raises(NotImplementedError):
+        per.slab_context(2)
 
     class LastOfFour(SingleWorld):
         rank, size = 3, 4

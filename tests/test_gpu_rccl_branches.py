@@ -52,6 +52,8 @@ def _run(worker, nranks, port, args, delay_ms=0, chunks=1):
     (8, "navier_stokes_with_forcing", "unfused", "64x64x64 pencil"),   # 4 x 2 ranks: the reference's default at 8
     (4, "navier_stokes_with_forcing", "fused", "64x32x64 pencil"),     # the one-call step on pencils
     (8, "navier_stokes_with_forcing", "fused", "64x64x64 nofilter pencil"),
+    (4, "navier_stokes_with_forcing", "fused", "64x32x64 yx"),         # x divided: packed x faces, blocks -> slabs
+    (8, "navier_stokes_with_forcing", "unfused", "64x32x64 zx"),
 ])
 def test_slab_flow_step_over_the_rccl_branches(nranks, flow_type, mode, grid):
     _run("_slab_worker.py", nranks, 29800 + nranks, [flow_type, mode] + grid.split())
@@ -85,6 +87,7 @@ def test_fft_and_doubled_domain_types_over_the_rccl_branches(nranks, grid, preci
     ("_slab_worker.py", 4, "navier_stokes_with_forcing fused 64x32x64 nofilter"),
     ("_slab_worker.py", 4, "navier_stokes_with_forcing unfused 64x32x64 pencil"),
     ("_slab_worker.py", 4, "navier_stokes_with_forcing fused 64x32x64 pencil"),
+    ("_slab_worker.py", 4, "navier_stokes_with_forcing fused 64x32x64 yx"),
     ("_rows_worker_2d.py", 4, "navier_stokes_with_forcing fused 64x48"),
 ])
 def test_transfers_held_back_by_milliseconds(worker, nranks, args):

@@ -46,6 +46,13 @@ def _failure_digest(out):
     (4, "navier_stokes_with_forcing", "fused", "64x32x64 nofilter pencil"),
     (8, "navier_stokes_with_forcing", "fused", "64x64x64 pencil"),
     (2, "navier_stokes_with_forcing", "fused", "32x32x32 yslab"),
+    # x divided: packed x faces in the exchange and the ghost sum, zero bands on physical x faces only, node ownership
+    # by x block, the Poisson solve routed through slabs; 16-byte row vectors where the local row allows (32 / 2 + 4)
+    (2, "navier_stokes", "unfused", "32x32x32 xslab"),
+    (4, "navier_stokes_with_forcing", "unfused", "64x32x64 xslab"),
+    (4, "navier_stokes_with_forcing", "fused", "64x32x64 yx"),
+    (4, "navier_stokes_with_forcing", "fused", "64x32x64 zx nofilter"),
+    (8, "navier_stokes_with_forcing", "fused", "64x32x64 zx"),
 ])
 def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
     _slab_run(nranks, flow_type, mode, grid, chunks=1)
