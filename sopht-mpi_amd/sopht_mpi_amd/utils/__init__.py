@@ -109,11 +109,11 @@ class MPIConstruct3D:
     """utils/mpi_utils_3d.py:7-83.
 
     ``rank_distribution`` follows the reference: 0 = distribute, 1 = keep aligned; the ranks are factored over
-    the distributed axes as MPI.Compute_dims does.  z-slabs ``(0, 1, 1)``, y-slabs ``(1, 0, 1)`` and pencils over
-    z and y ``(0, 0, 1)`` (the reference's default) are served by every operator; x stays whole there (the
-    transforms and the 16-byte row accesses of the kernels run along it).  A divided x axis and ``periodic_domain``
-    are served by the topology itself and by the ghost, field and Lagrangian communicators (what the reference's own
-    tests of these classes use); operators, Poisson solver and simulators raise NotImplementedError on them.
+    the distributed axes as MPI.Compute_dims does.  Every distribution is served; z-slabs ``(0, 1, 1)``, y-slabs
+    ``(1, 0, 1)`` and pencils over z and y ``(0, 0, 1)`` (the reference's default) are what the kernels are built for
+    (whole rows: the transforms and the 16-byte row accesses run along x).  ``periodic_domain`` is served by the
+    topology itself and by the ghost, field and Lagrangian communicators (what the reference's own test of the ghost
+    communicator uses); operators, Poisson solver and simulators raise NotImplementedError on it.
     ``None`` picks z-slabs here - fewer, larger messages on the point-to-point links of one node - where the
     reference picks pencils.  Uneven division raises RuntimeError like the reference (:51-57).
     """
@@ -213,11 +213,10 @@ def _start_transport(construct, ctx):
 
 
 class MPIGhostCommunicator3D:
-    """utils/mpi_utils_3d.py:86-1142.  On slabs and pencils whole faces travel, the z faces first and then the y faces
-    with the fresh z ghost planes in them, so the edges between two neighbours are always filled (``full_exchange``
-    changes nothing there; z-slabs have no diagonal neighbours at all).  On a general decomposition (x divided, or a
-    periodic domain) the exchange goes axis by axis through ``smi_halo_exchange_general``: faces, and with
-    ``full_exchange`` edges and vertices as well."""
+    """utils/mpi_utils_3d.py:86-1142.  On an unbounded domain whole faces travel, the z faces first, then the y faces
+    with the fresh z ghost planes in them, then the x faces, so the edges and vertices between neighbours are always
+    filled (``full_exchange`` changes nothing there).  On a periodic domain the exchange goes axis by axis through
+    ``smi_halo_exchange_general``: faces, and with ``full_exchange`` edges and vertices as well."""
 
     def __init__(self, ghost_size, mpi_construct, full_exchange=True):
         if ghost_size <= 0 or not isinstance(ghost_size, (int, np.integer)):
