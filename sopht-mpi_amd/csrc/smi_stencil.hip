@@ -1469,7 +1469,6 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
       SMI_CHECK_HIP(hipEventRecord(c->ev_a, c->stream));
       SMI_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_a, 0));
       SMI_CHECK(smi_halo_exchange2_on(c, f, 3, nullptr, 0, c->comm_stream));
-      SMI_CHECK_HIP(hipEventRecord(c->ev_b, c->comm_stream));
     } else {
       SMI_CHECK(smi_halo_exchange_impl(c, f, 3));
     }
@@ -1485,18 +1484,23 @@ static int run_curl(smi_ctx* c, void* out, void* f, double prefactor, const doub
       const TiledLaunch& t = tl;
       SMI_CHECK(allow_lds(k_curl_tiled<T>));
       const Const3<T> a = add ? Const3<T>{(T)add[0], (T)add[1], (T)add[2]} : Const3<T>{T(0), T(0), T(0)};
-      auto launch = [&](int chunk0, int count) {
+      auto launch = [&](int chunk0, int count, hipStream_t stream) {
         if (count <= 0) return;
-        k_curl_tiled<T><<<dim3(t.grid.x, count, 1), t.threads, t.lds_bytes, c->stream>>>(
+        k_curl_tiled<T><<<dim3(t.grid.x, count, 1), t.threads, t.lds_bytes, stream>>>(
             (T*)out, (const T*)f, (T)prefactor, G, t.zchunk, t.S, a, track_max ? (T*)c->umax_slots : nullptr, chunk0, 1);
       };
       if (overlap) {
-        launch(n_lo, nchunks - n_lo - n_hi);
+        // the end chunks follow the exchange on its stream, beside the interior chunks (see smi_advect_diffuse_impl)
+        // (they also follow what this stream has queued since the exchange began: the reset of the maximum slots)
+        SMI_CHECK_HIP(hipEventRecord(c->ev_a, c->stream));
+        SMI_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_a, 0));
+        launch(n_lo, nchunks - n_lo - n_hi, c->stream);
+        launch(0, n_lo, c->comm_stream);
+        launch(nchunks - n_hi, n_hi, c->comm_stream);
+        SMI_CHECK_HIP(hipEventRecord(c->ev_b, c->comm_stream));
         SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_b, 0));
-        launch(0, n_lo);
-        launch(nchunks - n_hi, n_hi);
       } else {
-        launch(0, nchunks);
+        launch(0, nchunks, c->stream);
       }
       added = true;
       if (track_max) {
@@ -1761,12 +1765,12 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   });
   const int zchunk = fused_zchunk(c, S.ntx * S.nty);
   const int nchunks = (c->pz + zchunk - 1) / zchunk;
-  auto launch = [&](int chunk0, int step, int count) {
+  auto launch = [&](int chunk0, int step, int count, hipStream_t stream) {
     dim3 grid(S.ntx * S.nty, count, 1);
     SMI_DISPATCH(c, {
-      k_advect_diffuse<T><<<grid, fused_threads<T>(), lds_bytes, c->stream>>>((T*)out, (const T*)velocity,
-                                                                             (const T*)vorticity, (T)pref_curl,
-                                                                             (T)pref_diff, G, zchunk, S, chunk0, step);
+      k_advect_diffuse<T><<<grid, fused_threads<T>(), lds_bytes, stream>>>((T*)out, (const T*)velocity,
+                                                                          (const T*)vorticity, (T)pref_curl,
+                                                                          (T)pref_diff, G, zchunk, S, chunk0, step);
     });
   };
   if (!smi_multi_rank(c)) {
@@ -1775,10 +1779,10 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
     // first and the last chunk) without the exchange between them - a single GPU can then check that they cover the
     // array exactly like the one launch
     if (c->opt_split_launch && nchunks >= 3) {
-      launch(1, 1, nchunks - 2);
-      launch(0, nchunks - 1, 2);
+      launch(1, 1, nchunks - 2, c->stream);
+      launch(0, nchunks - 1, 2, c->stream);
     } else {
-      launch(0, 1, nchunks);
+      launch(0, 1, nchunks, c->stream);
     }
     SMI_LAUNCH_CHECK();
     *ran = 1;
@@ -1799,7 +1803,6 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
     SMI_CHECK_HIP(hipEventRecord(c->ev_a, c->stream));
     SMI_CHECK_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_a, 0));
     SMI_CHECK(smi_halo_exchange2_on(c, velocity, 3, vorticity, 3, c->comm_stream));
-    SMI_CHECK_HIP(hipEventRecord(c->ev_b, c->comm_stream));
     return 0;
   };
   const int rc = exchange();
@@ -1808,11 +1811,16 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   {
     SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
     if (overlap) {
-      launch(1, 1, nchunks - 2);
+      // The first and the last chunk follow the exchange on ITS stream, next to the interior chunks on the compute
+      // stream: with a slab of a few dozen planes neither launch fills the chip (84 tiles per plane at 512^2: one and
+      // two chunks of the three are 84 and 168 workgroups for 256 CUs), and one after the other they took twice the
+      // time of one launch (0.32 against 0.16 ms for a 64-plane slab of 512^3).  Side by side they do.
+      launch(1, 1, nchunks - 2, c->stream);
+      launch(0, nchunks - 1, 2, c->comm_stream);
+      SMI_CHECK_HIP(hipEventRecord(c->ev_b, c->comm_stream));
       SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_b, 0));
-      launch(0, nchunks - 1, 2);
     } else {
-      launch(0, 1, nchunks);
+      launch(0, 1, nchunks, c->stream);
     }
     SMI_LAUNCH_CHECK();
   }

@@ -325,9 +325,18 @@ Job* new_job(ncclComm* comm) {
   return job;
 }
 
+// SMI_STANDIN_ALONE=1: one process plays ONE rank of a larger job and nothing travels - every send and receive is
+// accepted and dropped (received buffers keep what they held).  The library then runs its RCCL branches for that
+// rank (streams, events, groups, launch order) at the rank's share of the grid, which is how
+// tools/rank_local_step.py times the per-rank kernels of a multi-GPU step on one GPU.  Results are meaningless.
+bool alone() {
+  static const bool on = getenv("SMI_STANDIN_ALONE") && atoi(getenv("SMI_STANDIN_ALONE")) != 0;
+  return on;
+}
+
 // queues one group of sends and receives on their stream
 ncclResult_t submit(std::vector<Op>& ops) {
-  if (ops.empty()) return ncclSuccess;
+  if (ops.empty() || alone()) return ncclSuccess;
   ncclComm* comm = ops[0].comm;
   hipStream_t s = ops[0].stream;
   for (const Op& o : ops) {
@@ -396,6 +405,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   memcpy(tag, id.internal, 16);
   tag[16] = 0;
   c->dir = std::string("/tmp/smi_rccl_standin_") + tag;
+  c->listen_fd = -1;
+  if (alone()) {
+    *out = c;
+    return ncclSuccess;
+  }
   mkdir(c->dir.c_str(), 0700);
   auto address = [&](int r) {
     sockaddr_un a;
@@ -448,10 +462,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   for (int fd : c->fd)
     if (fd >= 0) close(fd);
   if (c->listen_fd >= 0) close(c->listen_fd);
-  char path[200];
-  snprintf(path, sizeof(path), "%s/r%d", c->dir.c_str(), c->rank);
-  unlink(path);
-  rmdir(c->dir.c_str());  // succeeds for the last rank to leave
+  if (!alone()) {
+    char path[200];
+    snprintf(path, sizeof(path), "%s/r%d", c->dir.c_str(), c->rank);
+    unlink(path);
+    rmdir(c->dir.c_str());  // succeeds for the last rank to leave
+  }
   delete c;
   return ncclSuccess;
 }
@@ -506,6 +522,10 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
   if (g_depth > 0) return fail(ncclInvalidUsage, "collectives inside a group are not modelled");
   if (type != ncclFloat64 && type != ncclFloat32) return fail(ncclInvalidArgument, "all-reduce of floats and doubles only");
   const size_t elem = type_size(type), bytes = count * elem;
+  if (alone()) {
+    if (recv != send && bytes) HIP_OK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s));
+    return ncclSuccess;
+  }
   Job* job = new_job(comm);
   job->count = count;
   job->elem = elem;
