@@ -637,6 +637,10 @@ struct PGeo {
   int nct, n2, n3;  // column kernels: tiles per row, second and third extent of the launch
   int zg;           // y kernels: consecutive planes one workgroup walks over
   int zl0;          // x kernels: first local plane of this launch (grid y counts planes from there)
+  // y kernels: planes of this launch.  yc_n = 0: all nz of them.  Otherwise the planes one z chunk of a transpose
+  // delivers or takes: local planes [yc_lo, yc_lo + yc_n) of every rank's slab, i.e. z = s nzl + yc_lo + i for
+  // s < P, i < yc_n, P yc_n planes in all, numbered s yc_n + i
+  int yc_lo, yc_n;
 };
 
 // The column kernels run on a one-dimensional grid whose blocks are dealt to the eight XCDs
@@ -733,8 +737,9 @@ using ZCfg = TileCfg<T, LG, false, WC, SMI_FFT_ZDENSE != 0>;
 struct YWalk {
   int z0, zg, nc, ntile;
   __device__ __forceinline__ YWalk(const PGeo& G, int zgroup) {
+    const int planes = G.yc_n ? G.P * G.yc_n : G.nz;
     z0 = zgroup * G.zg;
-    zg = min(G.zg, G.nz - z0);
+    zg = min(G.zg, planes - z0);
     nc = G.nc;
     ntile = zg * nc;
   }
@@ -742,6 +747,10 @@ struct YWalk {
     const int k = it / zg;
     c = G.c0 + k;
     z = z0 + (it - k * zg);
+    if (G.yc_n) {  // number within the chunk -> plane
+      const int sl = z / G.yc_n;
+      z = sl * G.nzl + G.yc_lo + (z - sl * G.yc_n);
+    }
   }
 };
 
@@ -1103,9 +1112,9 @@ struct PrunedState {
   // multi-rank: the transposes run on their own stream, one component at a time, so that they
   // overlap the transforms of the other components
   hipStream_t comm_stream = nullptr;
-  // per component: [0..3] forward chunk ready, [4] forward transpose done, [5] backward input ready,
-  // [6..9] backward chunk done
-  hipEvent_t ev[3][10] = {};
+  // per component and z chunk: [0..3] forward chunk ready, [4..7] forward chunk arrived, [8..11] backward chunk
+  // ready, [12..15] backward chunk arrived
+  hipEvent_t ev[3][16] = {};
   // host-staged test transport only: contiguous copies of one z chunk of every rank block
   void* stage[2] = {nullptr, nullptr};
 };
@@ -1278,8 +1287,23 @@ static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int 
     }
   } else {
     using Cfg = TileCfg<T, LG, false, WC>;
+    const int planes = G.yc_n ? G.P * G.yc_n : G.nz;
     G.zg = G.nc >= 3 ? 1 : 3;  // three tiles per workgroup
-    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, (G.nz + G.zg - 1) / G.zg, 1);
+    if (G.yc_n && G.nc < 3) {
+      // a chunk of planes is a short launch (one workgroup per CU): take the two to four planes per workgroup that
+      // leave the last round of the chip fullest
+      const long long cols = (ncols + Cfg::TS - 1) / Cfg::TS;
+      double best = 0.0;
+      for (int zg : {3, 2, 4}) {
+        const long long wgs = cols * ((planes + zg - 1) / zg), rounds = (wgs + 255) / 256;
+        const double fill = (double)wgs / (double)(rounds * 256);
+        if (fill > best + 0.02) {
+          best = fill;
+          G.zg = zg;
+        }
+      }
+    }
+    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, (planes + G.zg - 1) / G.zg, 1);
     const Cx<T>* tw = (const Cx<T>*)s->tw[1];
     if (which == 0) {
       SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG, WC>, Cfg::BYTES));
@@ -1293,14 +1317,18 @@ static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int 
   return 0;
 }
 
+// yc_n > 0 (y kernels only): the planes of one z chunk of a transpose, local planes [yc_lo, yc_lo + yc_n) of every slab
 template <typename T, int LG>
-static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc) {
+static int launch_cols(smi_ctx* c, PrunedState* s, int which, int c0, int nc, int yc_lo = 0, int yc_n = 0) {
   // which: 0 = y_fwd, 1 = z_conv, 2 = y_inv
   PGeo G = s->G;
   G.nc = nc;
   G.c0 = c0;
+  G.yc_lo = yc_lo;
+  G.yc_n = which == 1 ? 0 : yc_n;
+  const double share = G.yc_n ? (double)G.yc_n / (double)G.nzl : 1.0;
   const int slot = which == 0 ? PROF_FFT_Y_FWD : (which == 1 ? PROF_FFT_Z_CONV : PROF_FFT_Y_INV);
-  SmiProfScope prof(c, slot, (which == 1 ? 9.0 : 6.0) * nc * smi_S(c));
+  SmiProfScope prof(c, slot, (which == 1 ? 9.0 : 6.0) * nc * smi_S(c) * share);
   if (which == 1) return launch_cols_tiles<T, LG, SMI_FFT_ZCOLS>(c, s, which, G, 0, G.KXL);
   return launch_cols_tiles<T, LG, 0>(c, s, which, G, 0, G.KXL);
 }
@@ -1411,24 +1439,33 @@ int smi_pruned_solve(smi_poisson* p, void* solution, const void* rhs, int ncomp)
     }
     return 0;
   };
+  // The y passes work plane by plane, so they follow the transposes chunk by chunk as well: y_fwd of the planes that
+  // chunk j of a forward transpose delivered starts when that chunk has arrived, and chunk j of a backward transpose
+  // leaves as soon as y_inv has written its planes; only the z convolution needs a whole component.
   SMI_DISPATCH(c, {
     for (int k = 0; k < ncomp; ++k)
       for (int j = 0; j < C; ++j) {
         const int z0 = chunk_lo(j), nzc = chunk_lo(j + 1) - z0;
         LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, true, k, 1, (void*)rhs, z0, nzc)));)
-        SMI_CHECK(transfer(k, j, false, s->ev[k][j], j == C - 1 ? s->ev[k][4] : nullptr));
+        SMI_CHECK(transfer(k, j, false, s->ev[k][j], s->ev[k][4 + j]));
       }
     for (int k = 0; k < ncomp; ++k) {
-      if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[k][4], 0));
-      LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 0, k, 1)));)
+      for (int j = 0; j < C; ++j) {
+        const int z0 = chunk_lo(j), nzc = chunk_lo(j + 1) - z0;
+        if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[k][4 + j], 0));
+        LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 0, k, 1, z0, C > 1 ? nzc : 0)));)
+      }
       LG_SWITCH(s->lgz, SMI_CHECK((launch_cols<T, LG>(c, s, 1, k, 1)));)
-      LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 2, k, 1)));)
-      for (int j = 0; j < C; ++j) SMI_CHECK(transfer(k, j, true, j == 0 ? s->ev[k][5] : nullptr, s->ev[k][6 + j]));
+      for (int j = 0; j < C; ++j) {
+        const int z0 = chunk_lo(j), nzc = chunk_lo(j + 1) - z0;
+        LG_SWITCH(s->lgy, SMI_CHECK((launch_cols<T, LG>(c, s, 2, k, 1, z0, C > 1 ? nzc : 0)));)
+        SMI_CHECK(transfer(k, j, true, s->ev[k][8 + j], s->ev[k][12 + j]));
+      }
     }
     for (int k = 0; k < ncomp; ++k)
       for (int j = 0; j < C; ++j) {
         const int z0 = chunk_lo(j), nzc = chunk_lo(j + 1) - z0;
-        if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[k][6 + j], 0));
+        if (overlap) SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, s->ev[k][12 + j], 0));
         LG_SWITCH(s->lgx, SMI_CHECK((launch_rows<T, LG>(c, s, false, k, 1, solution, z0, nzc)));)
       }
   });
