@@ -63,7 +63,7 @@ prof = _lib.prof_collect(ctx)
 chunks = _lib.C.c_int(0)
 _lib.call("smi_ctx_get_option", ctx.handle, b"transpose_chunks", _lib.C.byref(chunks))
 kernels = {k: {"launches_per_step": v["launches"] / steps, "ms_per_step": v["ms"] / steps}
-           for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if k != "step"}
+           for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if k not in ("step", "flow_step")}
 print(json.dumps({
     "what": "rank-local work of one rank of a multi-GPU step, nothing travelling (see the file's docstring)",
     "grid": n, "ranks": nranks, "rank": rank, "steps": steps, "transpose_chunks": chunks.value,
