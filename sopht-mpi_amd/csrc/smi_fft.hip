@@ -1289,9 +1289,9 @@ static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int 
     using Cfg = TileCfg<T, LG, false, WC>;
     const int planes = G.yc_n ? G.P * G.yc_n : G.nz;
     G.zg = G.nc >= 3 ? 1 : 3;  // three tiles per workgroup
-    if (G.yc_n && G.nc < 3) {
-      // a chunk of planes is a short launch (one workgroup per CU): take the two to four planes per workgroup that
-      // leave the last round of the chip fullest
+    if (G.nc < 3) {
+      // one component of a rank's share, or a chunk of its planes, is a short launch (one workgroup per CU, a few
+      // rounds of the chip): take the two to four planes per workgroup that leave the last round fullest
       const long long cols = (ncols + Cfg::TS - 1) / Cfg::TS;
       double best = 0.0;
       for (int zg : {3, 2, 4}) {

@@ -686,8 +686,8 @@ constexpr int fused_threads() {
 template <typename T>
 __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __restrict__ out, const T* __restrict__ vel,
                                                                  const T* __restrict__ vort, T pref, T cdiff, Geo G,
-                                                                 int zchunk, FusedShape S, int chunk0,
-                                                                 int chunk_step) {
+                                                                 int zchunk, FusedShape S, int zbase, int zjump,
+                                                                 int zlimit) {
   extern __shared__ char smi_tile_smem[];
   T* lds = reinterpret_cast<T*>(smi_tile_smem);
   const Blk B = xcd_block<true>();
@@ -717,9 +717,9 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
       mB |= (unsigned)((yf && xc) || (ye && xf)) << e;
     }
   }
-  // chunk of this workgroup: chunk0 + chunk_step * (position along grid y), so that one launch can cover a run of
-  // chunks (step 1) or the first and the last one (step = number of chunks - 1)
-  const int z0 = (chunk0 + chunk_step * B.y) * zchunk, z1 = min(z0 + zchunk, G.pz);
+  // planes of this workgroup: zchunk of them from zbase + zjump * (position along grid y), below zlimit - so that one
+  // launch can cover a run of chunks (zjump = zchunk) or a short chunk at either end of the array (zjump = pz - zchunk)
+  const int z0 = zbase + zjump * B.y, z1 = min(z0 + zchunk, zlimit);
   auto plane_of = [&](int z) { return (long long)min(max(z, 0), G.pz - 1) * G.plane + q; };
   Vec3<T, 4> lu, lw;  // u and w of the plane two ahead, in flight
   Pack<T, 4> bPx, bPy, bCx, bCy, bCz, dummy;
@@ -1711,18 +1711,19 @@ int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorti
   return 0;
 }
 
-// Planes per workgroup of the fused kernel: one workgroup is resident per CU (its LDS tiles take two thirds of the
-// CU's 160 KB), so the launch should fill whole rounds of the chip, and every chunk re-reads four halo planes.
-static int fused_zchunk(const smi_ctx* c, int tiles_per_plane) {
+// Planes per workgroup of the fused kernel over a run of `planes` planes: one workgroup is resident per CU (its LDS
+// tiles take two thirds of the CU's 160 KB), so the launch should fill whole rounds of the chip, and every chunk
+// re-reads four halo planes.
+static int fused_zchunk(const smi_ctx* c, int tiles_per_plane, int planes) {
   static int cus[64] = {};
   int& n_cu = cus[c->device & 63];
   if (n_cu == 0 && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) n_cu = 256;
-  if (c->opt_fused_zchunk > 0) return c->opt_fused_zchunk;
-  int best = c->pz;
+  if (c->opt_fused_zchunk > 0) return c->opt_fused_zchunk < planes ? c->opt_fused_zchunk : planes;
+  int best = planes;
   double best_eff = 0.0;
-  for (int n = 1; n * 8 <= c->pz; ++n) {
-    const int zc = (c->pz + n - 1) / n;
-    const long long wgs = (long long)tiles_per_plane * ((c->pz + zc - 1) / zc);
+  for (int n = 1; n == 1 || n * 8 <= planes; ++n) {
+    const int zc = (planes + n - 1) / n;
+    const long long wgs = (long long)tiles_per_plane * ((planes + zc - 1) / zc);
     const long long rounds = (wgs + n_cu - 1) / n_cu;
     const double eff = (double)wgs / (double)(rounds * n_cu) * zc / (zc + 4.0);
     if (eff > best_eff) {
@@ -1763,26 +1764,40 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
     SMI_CHECK_HIP(hipFuncSetAttribute((const void*)k_advect_diffuse<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_bytes));
   });
-  const int zchunk = fused_zchunk(c, S.ntx * S.nty);
-  const int nchunks = (c->pz + zchunk - 1) / zchunk;
-  auto launch = [&](int chunk0, int step, int count, hipStream_t stream) {
+  // planes [zbase, zlimit) in `count` chunks of zchunk planes, the second and later ones zjump planes apart
+  auto launch = [&](int zbase, int zjump, int zchunk, int zlimit, int count, hipStream_t stream) {
     dim3 grid(S.ntx * S.nty, count, 1);
     SMI_DISPATCH(c, {
       k_advect_diffuse<T><<<grid, fused_threads<T>(), lds_bytes, stream>>>((T*)out, (const T*)velocity,
                                                                           (const T*)vorticity, (T)pref_curl,
-                                                                          (T)pref_diff, G, zchunk, S, chunk0, step);
+                                                                          (T)pref_diff, G, zchunk, S, zbase, zjump, zlimit);
     });
   };
+  auto launch_all = [&](hipStream_t stream) {
+    const int zchunk = fused_zchunk(c, S.ntx * S.nty, c->pz);
+    launch(0, zchunk, zchunk, c->pz, (c->pz + zchunk - 1) / zchunk, stream);
+  };
+  // The overlapped multi-rank schedule cuts the slab into the interior - every plane whose chunk cannot reach a ghost
+  // plane: a chunk reads planes z0 - 2 .. z1 + 1, so planes [g + 2, pz - g - 2) - and a short chunk of g + 2 planes at
+  // either end.  The interior is most of the work and needs nothing from the neighbours.
+  const int edge = c->g + 2;
+  const int inner = c->pz - 2 * edge;
+  const bool splittable = inner >= 8;
+  auto launch_interior = [&](hipStream_t stream) {
+    const int zchunk = fused_zchunk(c, S.ntx * S.nty, inner);
+    launch(edge, zchunk, zchunk, c->pz - edge, (inner + zchunk - 1) / zchunk, stream);
+  };
+  auto launch_edges = [&](hipStream_t stream) { launch(0, c->pz - edge, edge, c->pz, 2, stream); };
   if (!smi_multi_rank(c)) {
     SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
     // split_launch (SMI_FUSED_SPLIT_LAUNCH, smi_ctx_set_option): the two launches of the overlapped multi-rank schedule below (interior chunks, then the
-    // first and the last chunk) without the exchange between them - a single GPU can then check that they cover the
+    // two end chunks) without the exchange between them - a single GPU can then check that they cover the
     // array exactly like the one launch
-    if (c->opt_split_launch && nchunks >= 3) {
-      launch(1, 1, nchunks - 2, c->stream);
-      launch(0, nchunks - 1, 2, c->stream);
+    if (c->opt_split_launch && splittable) {
+      launch_interior(c->stream);
+      launch_edges(c->stream);
     } else {
-      launch(0, 1, nchunks, c->stream);
+      launch_all(c->stream);
     }
     SMI_LAUNCH_CHECK();
     *ran = 1;
@@ -1790,11 +1805,8 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   }
   const int saved_depth = c->halo_depth;
   c->halo_depth = c->g > 2 ? 2 : 0;  // two planes (0 = all g of them)
-  // a chunk reads planes z0 - 2 .. z1 + 1: only the first and the last one can reach a ghost plane when both of
-  // them are at least g + 2 planes long (the last one is the remainder of the division)
-  const int last_chunk = c->pz - (nchunks - 1) * zchunk;
   // (the ghost rows of a pencil's y faces reach every chunk: no overlap there)
-  const bool overlap = !c->exchange_cb && c->nranks_y == 1 && c->nranks_x == 1 && nchunks >= 3 && zchunk >= c->g + 2 && last_chunk >= c->g + 2;
+  const bool overlap = !c->exchange_cb && c->nranks_y == 1 && c->nranks_x == 1 && splittable;
   auto exchange = [&]() -> int {
     if (!overlap) return smi_halo_exchange2_impl(c, velocity, 3, vorticity, 3);
     // No RCCL call may be issued on c->stream while this exchange is pending on the communication stream (one
@@ -1811,16 +1823,17 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   {
     SmiProfScope prof(c, PROF_FUSED_ADVECT_DIFFUSE, 9.0 * smi_S(c));
     if (overlap) {
-      // The first and the last chunk follow the exchange on ITS stream, next to the interior chunks on the compute
-      // stream: with a slab of a few dozen planes neither launch fills the chip (84 tiles per plane at 512^2: one and
-      // two chunks of the three are 84 and 168 workgroups for 256 CUs), and one after the other they took twice the
-      // time of one launch (0.32 against 0.16 ms for a 64-plane slab of 512^3).  Side by side they do.
-      launch(1, 1, nchunks - 2, c->stream);
-      launch(0, nchunks - 1, 2, c->comm_stream);
+      // The end chunks follow the exchange on ITS stream, next to the interior chunks on the compute stream.  They are
+      // short on purpose: whatever a launch of up to one workgroup per CU holds takes the time of its longest
+      // workgroup, so end chunks as long as the interior ones (a 68-plane slab of 512^3 in three chunks of 23) made the
+      // step wait for the exchange AND for a third of the slab's planes behind it; now the interior chunks carry all
+      // planes but 2 (g + 2) and the ends cost 2 (g + 4) plane passes behind the exchange.
+      launch_interior(c->stream);
+      launch_edges(c->comm_stream);
       SMI_CHECK_HIP(hipEventRecord(c->ev_b, c->comm_stream));
       SMI_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ev_b, 0));
     } else {
-      launch(0, 1, nchunks, c->stream);
+      launch_all(c->stream);
     }
     SMI_LAUNCH_CHECK();
   }
