@@ -171,7 +171,9 @@ int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, 
 int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
 int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double pref_curl, double pref_diff,
-                            int* ran);
+                            int* ran, const double* penx);
+int smi_penalise_boundary_impl(smi_ctx* c, void* field, int ncomp, int width, const double* fac_lo,
+                               const double* fac_hi, int skip_x);
 int smi_curl_plus_const_impl(smi_ctx* c, void* curl, void* field, double prefactor, const double* add,
                              bool track_max = false);
 // forcing update and forcing reset restricted to the rows and planes the support box can reach

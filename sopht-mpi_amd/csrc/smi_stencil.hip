@@ -683,11 +683,21 @@ constexpr int fused_threads() {
   return sizeof(T) == 4 ? 1024 : 512;
 }
 
+// Penalisation of the x bands on the way out (penalise_field_boundary_mpi_3d.py:196-212, the first of the three
+// passes of the operator that follows this kernel in the step): with ghost + zone width = 4 a band is exactly the
+// first (last) 16-byte vector of a row and its source cell, layer 3 (layer px - 4), is an element of the same vector.
+// As a pass of its own it costs 0.1 ms at 512^3 (one partial line per row and side, read and written back).
+template <typename T>
+struct PenX {
+  int on_lo, on_hi;
+  T lo[4], hi[4];
+};
+
 template <typename T>
 __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __restrict__ out, const T* __restrict__ vel,
                                                                  const T* __restrict__ vort, T pref, T cdiff, Geo G,
                                                                  int zchunk, FusedShape S, int zbase, int zjump,
-                                                                 int zlimit) {
+                                                                 int zlimit, PenX<T> X) {
   extern __shared__ char smi_tile_smem[];
   T* lds = reinterpret_cast<T*>(smi_tile_smem);
   const Blk B = xcd_block<true>();
@@ -716,6 +726,8 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
       mA |= ((unsigned)(yc && xc) << e) | ((unsigned)(yd && xd) << (8 + e));
       mB |= (unsigned)((yf && xc) || (ye && xf)) << e;
     }
+    // bits 12, 13: this lane's vector is the low / high x band to be penalised
+    mA |= ((unsigned)(X.on_lo && x0 == 0) << 12) | ((unsigned)(X.on_hi && x0 == G.px - 4) << 13);
   }
   // planes of this workgroup: zchunk of them from zbase + zjump * (position along grid y), below zlimit - so that one
   // launch can cover a run of chunks (zjump = zchunk) or a short chunk at either end of the array (zjump = pz - zchunk)
@@ -798,6 +810,12 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
             const T left = e == 0 ? xm : cur.v[e - 1], right = e == 3 ? xp : cur.v[e + 1];
             const T val = cdiff * (right + left + yp.v[e] + ym.v[e] + nxt3[c]->v[e] + prv3[c]->v[e] - T(6) * cur.v[e]);
             o.v[e] = cur.v[e] + (((d >> e) & 1u) ? val : T(0));
+          }
+          if (mA & 0x3000u) {
+            const bool low = (mA & 0x1000u) != 0;
+            const T sv = low ? o.v[3] : o.v[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[e] = sv * (low ? X.lo[e] : X.hi[e]);
           }
           st<T, 4>(out + c * G.vol + zo, o);
         }
@@ -1744,8 +1762,10 @@ static int fused_zchunk(const smi_ctx* c, int tiles_per_plane, int planes) {
 // of the two exchanges of depth 1 of the two-pass path.  That exchange runs on the communication stream while the
 // chunks of planes that are out of reach of the ghost planes are already being computed; the first and the last
 // chunk follow once it has arrived.
+// penx (may be null): sine factors of the x bands (4 low, 4 high) of the boundary penalisation that follows, to be
+// applied on the way out; only valid for ghost + zone width = 4.
 int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double pref_curl, double pref_diff,
-                            int* ran) {
+                            int* ran, const double* penx) {
   *ran = 0;
   SMI_REQUIRE(out != velocity && out != vorticity, "advection-diffusion: output and input must not alias");
   if (c->opt_no_fused) return 0;
@@ -1768,9 +1788,18 @@ int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vortici
   auto launch = [&](int zbase, int zjump, int zchunk, int zlimit, int count, hipStream_t stream) {
     dim3 grid(S.ntx * S.nty, count, 1);
     SMI_DISPATCH(c, {
-      k_advect_diffuse<T><<<grid, fused_threads<T>(), lds_bytes, stream>>>((T*)out, (const T*)velocity,
-                                                                          (const T*)vorticity, (T)pref_curl,
-                                                                          (T)pref_diff, G, zchunk, S, zbase, zjump, zlimit);
+      PenX<T> X{};
+      if (penx) {
+        X.on_lo = c->phys_xlo;
+        X.on_hi = c->phys_xhi;
+        for (int e = 0; e < 4; ++e) {
+          X.lo[e] = (T)penx[e];
+          X.hi[e] = (T)penx[4 + e];
+        }
+      }
+      k_advect_diffuse<T><<<grid, fused_threads<T>(), lds_bytes, stream>>>(
+          (T*)out, (const T*)velocity, (const T*)vorticity, (T)pref_curl, (T)pref_diff, G, zchunk, S, zbase, zjump,
+          zlimit, X);
     });
   };
   auto launch_all = [&](hipStream_t stream) {
@@ -1847,7 +1876,7 @@ extern "C" int smi_advection_diffusion_update(smi_ctx* c, void* out, void* veloc
   SMI_REQUIRE(scratch != out && scratch != velocity && scratch != vorticity,
               "smi_advection_diffusion_update: the scratch array must not alias the others");
   int ran = 0;
-  SMI_CHECK(smi_advect_diffuse_impl(c, out, velocity, vorticity, prefactor, nu_dt_by_dx2, &ran));
+  SMI_CHECK(smi_advect_diffuse_impl(c, out, velocity, vorticity, prefactor, nu_dt_by_dx2, &ran, nullptr));
   if (ran) return 0;
   SMI_CHECK(smi_advect_vorticity_impl(c, scratch, velocity, vorticity, prefactor));
   return smi_diffusion_apply_impl(c, out, scratch, nu_dt_by_dx2, 3);
@@ -1879,6 +1908,12 @@ extern "C" int smi_divergence(smi_ctx* c, void* divergence, void* field, double 
 
 extern "C" int smi_penalise_boundary(smi_ctx* c, void* field, int ncomp, int width, const double* fac_lo,
                                      const double* fac_hi) {
+  return smi_penalise_boundary_impl(c, field, ncomp, width, fac_lo, fac_hi, 0);
+}
+
+// skip_x: the x bands have been penalised already (by the store of the kernel that produced `field`)
+int smi_penalise_boundary_impl(smi_ctx* c, void* field, int ncomp, int width, const double* fac_lo,
+                               const double* fac_hi, int skip_x) {
   SMI_REQUIRE(c && field && ncomp >= 1, "smi_penalise_boundary: bad argument");
   SMI_REQUIRE(width >= 0, "invalid zone width");
   if (width == 0) return 0;
@@ -1896,7 +1931,7 @@ extern "C" int smi_penalise_boundary(smi_ctx* c, void* field, int ncomp, int wid
   Geo G = make_geo(c);
   SmiProfScope prof(c, PROF_PENALISE, 0.0);
   SMI_DISPATCH(c, {
-    if (c->phys_xlo || c->phys_xhi)
+    if (!skip_x && (c->phys_xlo || c->phys_xhi))
       k_penalise<T, 0><<<blocks_for((long long)G.pz * G.py * ncomp), kBlock, 0, c->stream>>>((T*)field, G, ncomp, w,
                                                                                            fac, c->phys_xlo, c->phys_xhi);
     if (c->phys_ylo || c->phys_yhi)

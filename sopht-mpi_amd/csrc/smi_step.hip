@@ -156,8 +156,20 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
   const bool filter1 = filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE;
   void* w_new = vorticity;  // where the advected, diffused, filtered vorticity ends up
   int fused = 0;
+  // Without a filter the one-pass kernel writes what the penalisation reads: the x bands, the expensive ones as a
+  // pass of their own (a partial line per row and side), are then penalised in its store - the first of the three
+  // axis passes either way - when a band is one 16-byte vector (ghost + zone width = 4)
+  const int band = c->g + penalty_width;
+  const bool pen_x_in_store = !filter1 && penalty_width > 0 && band == 4;
+  double penx[8];
+  if (pen_x_in_store)
+    for (int e = 0; e < 4; ++e) {
+      penx[e] = fac_lo[e];       // axis x is the first row of the factor tables
+      penx[4 + e] = fac_hi[e];
+    }
   if (filter1 || (filter_order == 0 && result_in_buffer))
-    SMI_CHECK(smi_advect_diffuse_impl(c, buffer_vector, velocity, vorticity, pref_curl, pref_diff, &fused));
+    SMI_CHECK(smi_advect_diffuse_impl(c, buffer_vector, velocity, vorticity, pref_curl, pref_diff, &fused,
+                                      pen_x_in_store ? penx : nullptr));
   if (fused) {
     if (filter1) {
       SMI_CHECK(smi_filter_apply_impl(c, vorticity, buffer_vector, 3));
@@ -181,7 +193,7 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
       }
     }
   }
-  SMI_CHECK(smi_penalise_boundary(c, w_new, 3, penalty_width, fac_lo, fac_hi));
+  SMI_CHECK(smi_penalise_boundary_impl(c, w_new, 3, penalty_width, fac_lo, fac_hi, fused && pen_x_in_store));
   SMI_CHECK(smi_poisson_vector_solve_for(c, p, stream_func, w_new));
   // curl and the free stream in one pass over the velocity array
   SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream, /*track_max=*/true));
