@@ -288,8 +288,11 @@ int smi_reduce_sum_sq(smi_ctx* ctx, const void* field, int ncomp, double* out);
 int smi_poisson_create(smi_poisson** out, smi_ctx* ctx, int global_nz, int global_ny, int global_nx,
                        double dx, double x_range, int backend);
 /* 1 when smi_poisson_create would accept this global grid on `nranks` slabs with this back end, else 0: the
- * rocFFT back end takes any grid on one rank; the pruned one needs nx, ny and nz to be powers of two from 8
- * to 2048 or one of 192, 320, 384, 640, 768.  No counterpart in the reference (mpi4py-fft plans any size). */
+ * rocFFT back end takes any grid whose planes divide over the ranks (one rank: the doubled grid whole, as the
+ * reference's solver forms it; z-slabs: a divided transform - rows where they live, an all-to-all to spectral
+ * columns, doubled (2nz, 2ny) planes per rank - in place of mpi4py-fft's, fft_mpi_3d.py:27-48); the pruned one
+ * needs nx, ny and nz to be powers of two from 8 to 2048 or one of 192, 320, 384, 640, 768.  No counterpart in
+ * the reference (mpi4py-fft plans any size). */
 int smi_poisson_supports(int global_nz, int global_ny, int global_nx, int nranks, int backend);
 int smi_poisson_destroy(smi_poisson* p);
 int smi_poisson_solve(smi_poisson* p, void* solution, const void* rhs);

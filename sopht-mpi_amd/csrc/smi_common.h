@@ -168,7 +168,7 @@ int smi_y_face_exchange(smi_ctx* ctx, void* field, int ncomp, int depth, bool su
 int smi_p2p_exchange(smi_ctx* c, int nsend, const int* send_peers, const void* const* sends, int nrecv,
                      const int* recv_peers, void* const* recvs, size_t bytes);
 int smi_diffusion_apply_impl(smi_ctx* c, void* out, void* in, double prefactor, int ncomp);
-int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp);
+int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp, const double* penx, int* pen_done);
 int smi_advect_vorticity_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double prefactor);
 int smi_advect_diffuse_impl(smi_ctx* c, void* out, void* velocity, void* vorticity, double pref_curl, double pref_diff,
                             int* ran, const double* penx);

@@ -684,7 +684,7 @@ constexpr int fused_threads() {
 }
 
 // Penalisation of the x bands on the way out (penalise_field_boundary_mpi_3d.py:196-212, the first of the three
-// passes of the operator that follows this kernel in the step): with ghost + zone width = 4 a band is exactly the
+// passes of the operator that follows the one-pass kernels in the step): with ghost + zone width = 4 a band is exactly the
 // first (last) 16-byte vector of a row and its source cell, layer 3 (layer px - 4), is an element of the same vector.
 // As a pass of its own it costs 0.1 ms at 512^3 (one partial line per row and side, read and written back).
 template <typename T>
@@ -692,6 +692,17 @@ struct PenX {
   int on_lo, on_hi;
   T lo[4], hi[4];
 };
+
+// the low / high x band as one vector (v[3] resp. v[0] is its source cell): band = 1 / 2
+template <typename T>
+__device__ __forceinline__ void pen_x_apply(Pack<T, 4>& o, int band, const PenX<T>& X) {
+  if (band) {
+    const bool low = band == 1;
+    const T sv = low ? o.v[3] : o.v[0];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = sv * (low ? X.lo[e] : X.hi[e]);
+  }
+}
 
 template <typename T>
 __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __restrict__ out, const T* __restrict__ vel,
@@ -811,12 +822,7 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
             const T val = cdiff * (right + left + yp.v[e] + ym.v[e] + nxt3[c]->v[e] + prv3[c]->v[e] - T(6) * cur.v[e]);
             o.v[e] = cur.v[e] + (((d >> e) & 1u) ? val : T(0));
           }
-          if (mA & 0x3000u) {
-            const bool low = (mA & 0x1000u) != 0;
-            const T sv = low ? o.v[3] : o.v[0];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o.v[e] = sv * (low ? X.lo[e] : X.hi[e]);
-          }
+          pen_x_apply(o, (int)(mA >> 12) & 3, X);
           st<T, 4>(out + c * G.vol + zo, o);
         }
       }
@@ -1227,13 +1233,19 @@ __global__ void __launch_bounds__(kBlock) k_filter_pass(T* __restrict__ flux, co
 // from the same exchanged values); [zlo_e, zhi_e] and [ylo_e, yhi_e] are those extended ranges.
 template <typename T, int V>
 __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, const T* __restrict__ f, Geo G,
-                                                        int zchunk, int zlo_e, int zhi_e) {
+                                                        int zchunk, int zlo_e, int zhi_e, PenX<T> X) {
   const Blk B = xcd_block<false>();
   long long q;
   int y, x0;
   if (!lane_pos<V>(G, B, q, y, x0)) return;
   f += (long long)B.z * G.vol + q;
   out += (long long)B.z * G.vol + q;
+  // x bands penalised on the way out (V = 4 only): every store of this kernel goes through put()
+  const int band = V == 4 ? ((X.on_lo && x0 == 0) ? 1 : ((X.on_hi && x0 == G.px - 4) ? 2 : 0)) : 0;
+  auto put = [&](int z, Pack<T, V> o) {
+    if constexpr (V == 4) pen_x_apply(o, band, X);
+    st<T, V>(out + z * G.plane, o);
+  };
   bool xc[V], anyx = false;
 #pragma unroll
   for (int e = 0; e < V; ++e) {
@@ -1247,7 +1259,7 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
   const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
   const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
   if (!(yc && anyx) || zs > ze) {
-    for (int z = z0; z < z1; ++z) st<T, V>(out + z * G.plane, ld<T, V>(f + z * G.plane));
+    for (int z = z0; z < z1; ++z) put(z, ld<T, V>(f + z * G.plane));
     return;
   }
   // Lx f of one row of plane zp (masked to the row's cells inside D)
@@ -1273,7 +1285,7 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
     for (int e = 0; e < V; ++e) r.v[e] = xc[e] ? T(0.25) * (-c.v[e] - a.v[e] + T(2) * b.v[e]) : T(0);
     return r;
   };
-  for (int z = z0; z < zs; ++z) st<T, V>(out + z * G.plane, ld<T, V>(f + z * G.plane));
+  for (int z = z0; z < zs; ++z) put(z, ld<T, V>(f + z * G.plane));
   Pack<T, V> prev = f2_plane(zs - 1), cur = f2_plane(zs);
   for (int z = zs; z <= ze; ++z) {
     const Pack<T, V> nxt = f2_plane(z + 1);
@@ -1284,11 +1296,11 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
       const T flux = xc[e] ? T(0.25) * (-nxt.v[e] - prev.v[e] + T(2) * cur.v[e]) : T(0);
       o.v[e] = fc.v[e] - flux;
     }
-    st<T, V>(out + z * G.plane, o);
+    put(z, o);
     prev = cur;
     cur = nxt;
   }
-  for (int z = ze + 1; z < z1; ++z) st<T, V>(out + z * G.plane, ld<T, V>(f + z * G.plane));
+  for (int z = ze + 1; z < z1; ++z) put(z, ld<T, V>(f + z * G.plane));
 }
 
 // zero the outer (g + width) layers next to physical faces (zero_bands of the wrappers)
@@ -1960,19 +1972,32 @@ static int filter_pass(smi_ctx* c, const Geo& G, int axis, T* flux, T* src) {
 }
 
 // out = in - Lz(Ly(Lx in)): the multiplicative filter of order 1 in one pass per component
-int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp) {
+// penx (may be null): factors of the x bands of the penalisation that follows (4 low, 4 high; ghost + zone width = 4),
+// applied on the way out where the kernel stores 16-byte vectors; *pen_done says whether that happened.
+int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp, const double* penx, int* pen_done) {
   SMI_REQUIRE(out != in, "filter: output and input must not alias");
+  if (pen_done) *pen_done = 0;
   if (smi_multi_rank(c)) SMI_CHECK(smi_halo_exchange_impl(c, in, ncomp));
   Geo G = make_geo(c);
   const int zlo_e = G.zlo_c - (c->phys_zlo ? 0 : 1), zhi_e = G.zhi_c + (c->phys_zhi ? 0 : 1);
   SmiProfScope prof(c, PROF_FILTER, 2.0 * ncomp * smi_S(c));
   SMI_DISPATCH(c, {
+    PenX<T> X{};
     if (vec_ok<T>(c, out, in)) {
+      if (penx && pen_done) {
+        X.on_lo = c->phys_xlo;
+        X.on_hi = c->phys_xhi;
+        for (int e = 0; e < 4; ++e) {
+          X.lo[e] = (T)penx[e];
+          X.hi[e] = (T)penx[4 + e];
+        }
+        *pen_done = 1;
+      }
       LaunchShape s = plan<4>(c, ncomp);
-      k_filter_fused<T, 4><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e);
+      k_filter_fused<T, 4><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e, X);
     } else {
       LaunchShape s = plan<1>(c, ncomp);
-      k_filter_fused<T, 1><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e);
+      k_filter_fused<T, 1><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e, X);
     }
   });
   SMI_LAUNCH_CHECK();
@@ -2009,7 +2034,7 @@ extern "C" int smi_laplacian_filter_w(smi_ctx* c, void* field, int ncomp, void* 
     const size_t stride = c->vol * smi_elem_size(c);
     for (int k = 0; k < ncomp; ++k) {
       void* fk = (char*)field + (size_t)k * stride;
-      SMI_CHECK(smi_filter_apply_impl(c, field_buffer, fk, 1));
+      SMI_CHECK(smi_filter_apply_impl(c, field_buffer, fk, 1, nullptr, nullptr));
       SMI_CHECK(smi_elementwise_copy(c, fk, field_buffer, 1));
     }
     return 0;

@@ -156,11 +156,13 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
   const bool filter1 = filter_order == 1 && filter_type == SMI_FILTER_MULTIPLICATIVE;
   void* w_new = vorticity;  // where the advected, diffused, filtered vorticity ends up
   int fused = 0;
-  // Without a filter the one-pass kernel writes what the penalisation reads: the x bands, the expensive ones as a
-  // pass of their own (a partial line per row and side), are then penalised in its store - the first of the three
-  // axis passes either way - when a band is one 16-byte vector (ghost + zone width = 4)
+  // The x bands of the penalisation are the expensive ones as a pass of their own (a partial line per row and side).
+  // When a band is one 16-byte vector (ghost + zone width = 4) they are penalised in the store of the kernel that
+  // writes what the penalisation reads - the one-pass kernel, or the one-pass filter behind it - which is the
+  // first of the operator's three axis passes either way.
   const int band = c->g + penalty_width;
-  const bool pen_x_in_store = !filter1 && penalty_width > 0 && band == 4;
+  const bool pen_x_in_store = penalty_width > 0 && band == 4;
+  int pen_x_done = 0;
   double penx[8];
   if (pen_x_in_store)
     for (int e = 0; e < 4; ++e) {
@@ -169,13 +171,14 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
     }
   if (filter1 || (filter_order == 0 && result_in_buffer))
     SMI_CHECK(smi_advect_diffuse_impl(c, buffer_vector, velocity, vorticity, pref_curl, pref_diff, &fused,
-                                      pen_x_in_store ? penx : nullptr));
+                                      pen_x_in_store && !filter1 ? penx : nullptr));
   if (fused) {
     if (filter1) {
-      SMI_CHECK(smi_filter_apply_impl(c, vorticity, buffer_vector, 3));
+      SMI_CHECK(smi_filter_apply_impl(c, vorticity, buffer_vector, 3, pen_x_in_store ? penx : nullptr, &pen_x_done));
     } else {
       w_new = buffer_vector;
       *result_in_buffer = 1;
+      pen_x_done = pen_x_in_store;
     }
   } else {
     SMI_CHECK(smi_advect_vorticity_impl(c, buffer_vector, velocity, vorticity, pref_curl));
@@ -183,7 +186,7 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
       // the common filter setting runs as one more single pass: diffuse into the (still dead) stream function
       // array, filter from there back into vorticity
       SMI_CHECK(smi_diffusion_apply_impl(c, stream_func, buffer_vector, pref_diff, 3));
-      SMI_CHECK(smi_filter_apply_impl(c, vorticity, stream_func, 3));
+      SMI_CHECK(smi_filter_apply_impl(c, vorticity, stream_func, 3, pen_x_in_store ? penx : nullptr, &pen_x_done));
     } else {
       SMI_CHECK(smi_diffusion_apply_impl(c, vorticity, buffer_vector, pref_diff, 3));
       if (filter_order > 0) {
@@ -193,7 +196,7 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
       }
     }
   }
-  SMI_CHECK(smi_penalise_boundary_impl(c, w_new, 3, penalty_width, fac_lo, fac_hi, fused && pen_x_in_store));
+  SMI_CHECK(smi_penalise_boundary_impl(c, w_new, 3, penalty_width, fac_lo, fac_hi, pen_x_done));
   SMI_CHECK(smi_poisson_vector_solve_for(c, p, stream_func, w_new));
   // curl and the free stream in one pass over the velocity array
   SMI_CHECK(smi_curl_plus_const_impl(c, velocity, stream_func, pref_vel, free_stream, /*track_max=*/true));

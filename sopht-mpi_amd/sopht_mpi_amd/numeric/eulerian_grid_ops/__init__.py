@@ -310,8 +310,9 @@ class UnboundedPoissonSolverMPI3D:
     """poisson_solver_3d/UnboundedPoissonSolverMPI3D.py:14-187.
 
     ``backend``: "rocfft" restates the reference literally on one GPU (zero-padded doubled
-    domain through rocFFT); "pruned" uses the library's own zero-padding-aware FFT passes and
-    is the only one that runs on several slabs.  Default: pruned when available for the grid.
+    domain through rocFFT) and divides the transform over z-slabs on several (any grid size);
+    "pruned" uses the library's own zero-padding-aware FFT passes, for the sizes it has plans
+    for.  Default: pruned when available for the grid.
     """
 
     def __init__(self, grid_size_z, grid_size_y, grid_size_x, mpi_construct, ghost_size, x_range=1.0,

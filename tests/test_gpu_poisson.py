@@ -163,7 +163,10 @@ def test_poisson_supports_reports_what_create_accepts(smi):
             else:
                 with pytest.raises(SophtMIError):
                     _solver(smi, ctx, shape, 1.0, np.float32, backend)
-    assert not lib.smi_poisson_supports(16, 16, 16, 2, CODES["rocfft"])   # slabs need the pruned back end
+    assert lib.smi_poisson_supports(16, 16, 16, 2, CODES["rocfft"])   # slabs: the divided transform, any size
+    assert lib.smi_poisson_supports(24, 20, 36, 2, CODES["rocfft"])
+    assert not lib.smi_poisson_supports(24, 20, 36, 2, CODES["pruned"])
+    assert not lib.smi_poisson_supports(25, 20, 36, 2, CODES["rocfft"])   # planes must divide over the ranks
     assert lib.smi_poisson_supports(16, 16, 16, 2, CODES["pruned"])
 
 

@@ -54,9 +54,18 @@ def _run(worker, nranks, port, args, delay_ms=0, chunks=1):
     (8, "navier_stokes_with_forcing", "fused", "64x64x64 nofilter pencil"),
     (4, "navier_stokes_with_forcing", "fused", "64x32x64 yx"),         # x divided: packed x faces, blocks -> slabs
     (8, "navier_stokes_with_forcing", "unfused", "64x32x64 zx"),
+    (4, "navier_stokes_with_forcing", "fused", "48x24x40 nofilter"),   # no pruned plan: divided rocFFT transform
 ])
 def test_slab_flow_step_over_the_rccl_branches(nranks, flow_type, mode, grid):
     _run("_slab_worker.py", nranks, 29800 + nranks, [flow_type, mode] + grid.split())
+
+
+@pytest.mark.parametrize("nranks,args,delay_ms", [(2, "24x20x36", 0), (4, "16x32x64 double", 4),
+                                                  (4, "24x24x40 pencil", 4)])
+def test_poisson_solver_on_ranks_over_the_rccl_branches(nranks, args, delay_ms):
+    """Both back ends of the solver type on slabs and pencils: the all-to-alls of the divided rocFFT transform on the
+    compute stream, those of the pruned transform on its communication stream, with transfers held back."""
+    _run("_poisson_ranks_worker.py", nranks, 29840 + nranks, args.split(), delay_ms=delay_ms)
 
 
 @pytest.mark.parametrize("nranks,flow_type,mode,grid", [

@@ -53,6 +53,11 @@ def _failure_digest(out):
     (4, "navier_stokes_with_forcing", "fused", "64x32x64 yx"),
     (4, "navier_stokes_with_forcing", "fused", "64x32x64 zx nofilter"),
     (8, "navier_stokes_with_forcing", "fused", "64x32x64 zx"),
+    # sizes without a pruned plan (24, 20, 36, 40, 48 points): the rocFFT back end's divided transform - rows where
+    # they live, all-to-all to spectral columns, doubled (2nz, 2ny) planes per rank
+    (2, "navier_stokes", "fused", "24x20x36"),
+    (4, "navier_stokes_with_forcing", "fused", "48x24x40 nofilter"),
+    (4, "navier_stokes", "fused", "24x24x40 pencil"),
 ])
 def test_slab_flow_step_matches_oracle(nranks, flow_type, mode, grid):
     _slab_run(nranks, flow_type, mode, grid, chunks=1)
@@ -68,6 +73,25 @@ def test_slab_flow_step_with_chunked_transposes(nranks, chunks, flow_type, mode,
     """The spectral transposes in 2 or 4 chunks of planes (SMI_FFT_TRANSPOSE_CHUNKS) over the host-staged transport:
     the sliced exchange layout and the chunk-wise x transforms against the single-rank oracle."""
     _slab_run(nranks, flow_type, mode, grid, chunks=chunks)
+
+
+@pytest.mark.parametrize("nranks,args", [
+    (2, "24x20x36"), (2, "24x20x36 double"), (4, "16x32x64"), (4, "16x32x64 double"), (4, "40x12x17"),
+    (3, "27x10x12 double"), (4, "24x24x40 pencil"), (4, "32x32x32 pencil double"),
+])
+def test_poisson_solver_on_ranks_matches_oracle(nranks, args):
+    """The solver type by itself on z-slabs and through the pencil route: the divided rocFFT transform on sizes with
+    and without pruned plans (odd row lengths and three ranks included), the pruned back end where it has plans."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["SOPHT_MI_TRANSPORT"] = "host"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(29650 + nranks),
+           os.path.join(ROOT, "tests", "_poisson_ranks_worker.py")] + args.split()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, _failure_digest(out)
+    for r in range(nranks):
+        assert f"rank {r} ok" in out.stdout
 
 
 def _slab_run(nranks, flow_type, mode, grid, chunks):
