@@ -86,7 +86,7 @@ def test_poisson_solver_on_ranks_matches_oracle(nranks, args):
     env.pop("WORLD_SIZE", None)
     env["SOPHT_MI_TRANSPORT"] = "host"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(29650 + nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(29670 + nranks),
            os.path.join(ROOT, "tests", "_poisson_ranks_worker.py")] + args.split()
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, _failure_digest(out)
