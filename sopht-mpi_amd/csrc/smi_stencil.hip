@@ -676,11 +676,18 @@ struct FusedShape {
   int ntx, nty;    // tiles per plane
   int pitch;       // LDS row pitch in elements (the lane's vector starts at column 4 + 4 * its index)
 };
-// Lanes per workgroup: 1024 in single precision (128 registers per lane); double precision holds twice the register
-// state per lane and runs 512 lanes (256 registers), with LDS tiles of the same byte size.
+// Lanes per workgroup: 768 in single precision (twelve waves, three per SIMD: up to 168 registers per lane; the kernel
+// holds 157).  With 1024 lanes (128 registers) it spilled five to seven registers whose reloads - evicted from the L2
+// by the planes streaming through between two uses - showed as 0.4 GB of extra fetches per launch at 512^3; measured
+// 1024 -> 768 lanes: 1.33 -> 1.24 ms at 512^3, 0.60 -> 0.49 ms at 384^3, and with the next plane requested a whole step
+// ahead, which 168 registers allow, 1.21 and 0.48 ms.  Double precision holds twice the register state per lane and
+// runs 512 lanes (256 registers), with LDS tiles of the same byte size.
+#ifndef SMI_FUSED_LANES_F32
+#define SMI_FUSED_LANES_F32 768
+#endif
 template <typename T>
 constexpr int fused_threads() {
-  return sizeof(T) == 4 ? 1024 : 512;
+  return sizeof(T) == 4 ? SMI_FUSED_LANES_F32 : 512;
 }
 
 // Penalisation of the x bands on the way out (penalise_field_boundary_mpi_3d.py:196-212, the first of the three
@@ -768,12 +775,18 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
       st<T, 4>(tw + 2 * comp + off, Wk.z);
     }
     __syncthreads();
-    // b and w of plane k + 2 from the loads issued half a step ago (the request for plane k + 3 follows once the
-    // registers of the curl below are free again: with both in flight the allocation spills)
+    // b and w of plane k + 2 from the loads issued a step (double precision: half a step) ago
     Pack<T, 4> bNx, bNy, bNz;
     cross3(lu.x, lu.y, lu.z, lw.x, lw.y, lw.z, bNx, bNy, bNz);
     const Vec3<T, 4> wN = lw;
     Vec3<T, 4> Wn = wC;
+    // u and w of plane k + 3: single precision requests them here, a whole curl and diffusion ahead of their use (its
+    // 168 registers hold both sets in flight); double precision, which would spill, once the curl's registers are free
+    constexpr bool EARLY = sizeof(T) == 4;
+    if (EARLY && k + 3 <= z1 + 1) {  // uniform
+      lu = ld3<T, 4>(vel + plane_of(k + 3), G.vol);
+      lw = ld3<T, 4>(vort + plane_of(k + 3), G.vol);
+    }
     if (lane_on) {
       // w* of plane k + 1
       const int j = k + 1;
@@ -797,7 +810,7 @@ __global__ void __launch_bounds__(fused_threads<T>()) k_advect_diffuse(T* __rest
         Wn.z.v[e] = on ? wC.z.v[e] + cz : wC.z.v[e];
       }
     }
-    if (k + 3 <= z1 + 1) {  // uniform
+    if (!EARLY && k + 3 <= z1 + 1) {  // uniform
       lu = ld3<T, 4>(vel + plane_of(k + 3), G.vol);
       lw = ld3<T, 4>(vort + plane_of(k + 3), G.vol);
     }
