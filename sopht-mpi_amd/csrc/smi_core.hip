@@ -30,7 +30,7 @@ static int ctx_allocate(smi_ctx* c) {
   SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
   SMI_CHECK_HIP(hipMalloc(&c->red_partials, sizeof(double) * (kRedBlocks + 8)));
-  SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, sizeof(double) * 8, hipHostMallocDefault));
+  SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, sizeof(double) * (8 + kUmaxSlots), hipHostMallocDefault));
   SMI_CHECK_HIP(hipMalloc(&c->fac_dev, sizeof(double) * 6 * 64));
   SMI_CHECK_HIP(hipMalloc(&c->umax_slots, sizeof(unsigned long long) * kUmaxSlots));
   for (int i = 0; i < 2; ++i) SMI_CHECK_HIP(hipMalloc(&c->halo_recv[i], c->halo_cap));
@@ -604,9 +604,11 @@ extern "C" int smi_step_velocity_max_abs_sum(smi_ctx* c, const void* velocity, d
   SMI_REQUIRE(c->umax_valid, "smi_step_velocity_max_abs_sum: no fused step has recorded the maximum");
   SMI_REQUIRE(c->umax_field == velocity,
               "smi_step_velocity_max_abs_sum: the recorded maximum belongs to another velocity array of this context");
-  unsigned long long bits[kUmaxSlots];
+  // into the context's pinned host words (behind those of the reductions): a copy into pageable memory is staged
+  // and costs the loop that asks for dt every step some ten microseconds more
+  const unsigned long long* bits = reinterpret_cast<const unsigned long long*>(c->red_host + 8);
   const size_t es = smi_elem_size(c);
-  SMI_CHECK_HIP(hipMemcpyAsync(bits, c->umax_slots, es * kUmaxSlots, hipMemcpyDeviceToHost, c->stream));
+  SMI_CHECK_HIP(hipMemcpyAsync(c->red_host + 8, c->umax_slots, es * kUmaxSlots, hipMemcpyDeviceToHost, c->stream));
   SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
   double m = c->umax_band;
   for (int i = 0; i < kUmaxSlots; ++i) {
