@@ -161,7 +161,7 @@ static int flow_step_body(smi_ctx* c, smi_poisson* p, void* vorticity, void* vel
   // writes what the penalisation reads - the one-pass kernel, or the one-pass filter behind it - which is the
   // first of the operator's three axis passes either way.
   const int band = c->g + penalty_width;
-  const bool pen_x_in_store = penalty_width > 0 && band == 4;
+  const bool pen_x_in_store = penalty_width > 0 && band == 4 && fac_lo && fac_hi;  // (null tables: reported below)
   int pen_x_done = 0;
   double penx[8];
   if (pen_x_in_store)
