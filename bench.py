@@ -147,13 +147,39 @@ def cpu_baseline(grid, steps, warmup):
     }
 
 
+# sopht_mpi_amd.world listens on MASTER_PORT + this + rank (checked against the package once the ranks have imported
+# it; the launcher itself imports nothing that could touch the GPU)
+WORLD_PORT_OFFSET = 101
+
+
+def free_rendezvous_port(n_ranks):
+    """A rendezvous port below the range the system hands out to outgoing connections, free right now together with
+    the ports the ranks' own host-side world will listen on (sopht_mpi_amd.world: the port offset by a constant, one
+    per rank)."""
+    import random
+
+    def is_free(port):
+        with socket.socket() as sock:
+            sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                sock.bind(("127.0.0.1", port))
+            except OSError:
+                return False
+        return True
+
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e3))
+    for _ in range(200):
+        port = rng.randrange(20000, 28000)
+        if is_free(port) and all(is_free(port + WORLD_PORT_OFFSET + r) for r in range(n_ranks)):
+            return port
+    raise SystemExit("bench: found no free rendezvous port")
+
+
 def launch_ranks(n_gpus, argv, timeout_s):
     """`python bench.py --gpus N` without a launcher around it: start the N rank processes (torch.distributed.run,
     one per GPU, rendezvous on 127.0.0.1) as a CHILD process - nothing in this process has touched the GPU - pass its
     output through and return its exit status.  A child that outlives `timeout_s` is ended with its process group."""
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    port = free_rendezvous_port(n_gpus)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -242,7 +268,10 @@ def main():
 
     from sopht_mpi_amd import _lib
     from sopht_mpi_amd.simulator import UnboundedFlowSimulator3D
+    from sopht_mpi_amd import world as world_module
     from sopht_mpi_amd.world import get_world
+
+    assert world_module._PORT_OFFSET == WORLD_PORT_OFFSET
 
     watchdog = Watchdog(args.gpus > 1, int(os.environ.get("RANK", "0")))
     watchdog.phase("rendezvous, context and RCCL set-up", 300)

@@ -641,6 +641,9 @@ struct PGeo {
   // delivers or takes: local planes [yc_lo, yc_lo + yc_n) of every rank's slab, i.e. z = s nzl + yc_lo + i for
   // s < P, i < yc_n, P yc_n planes in all, numbered s yc_n + i
   int yc_lo, yc_n;
+  // column kernels: the third extent of the launch runs over the components, one per workgroup, instead of every
+  // workgroup walking over all of them (small grids: more, shorter workgroups)
+  int csplit;
 };
 
 // The column kernels run on a one-dimensional grid whose blocks are dealt to the eight XCDs
@@ -736,16 +739,18 @@ using ZCfg = TileCfg<T, LG, false, WC, SMI_FFT_ZDENSE != 0>;
 // that latency.
 struct YWalk {
   int z0, zg, nc, ntile;
-  __device__ __forceinline__ YWalk(const PGeo& G, int zgroup) {
+  int c0;
+  __device__ __forceinline__ YWalk(const PGeo& G, int zgroup, int k3) {
     const int planes = G.yc_n ? G.P * G.yc_n : G.nz;
     z0 = zgroup * G.zg;
     zg = min(G.zg, planes - z0);
-    nc = G.nc;
+    nc = G.csplit ? 1 : G.nc;
+    c0 = G.csplit ? G.c0 + k3 : G.c0;
     ntile = zg * nc;
   }
   __device__ __forceinline__ void tile(const PGeo& G, int it, int& c, int& z) const {
     const int k = it / zg;
-    c = G.c0 + k;
+    c = c0 + k;
     z = z0 + (it - k * zg);
     if (G.yc_n) {  // number within the chunk -> plane
       const int sl = z / G.yc_n;
@@ -761,7 +766,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false, WC>::NT), (TileCfg<T, L
   FFT_KERNEL_PROLOGUE_T(false, YC_)
   int ct, zgroup, k3;
   if (!col_tile<Cfg::PF>(G, ct, zgroup, k3)) return;
-  const YWalk W(G, zgroup);
+  const YWalk W(G, zgroup, k3);
   const int col = G.colbase + ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
@@ -811,7 +816,7 @@ __global__ void __launch_bounds__((TileCfg<T, LG, false, WC>::NT), (TileCfg<T, L
   FFT_KERNEL_PROLOGUE_T(false, YC_)
   int ct, zgroup, k3;
   if (!col_tile<Cfg::PF>(G, ct, zgroup, k3)) return;
-  const YWalk W(G, zgroup);
+  const YWalk W(G, zgroup, k3);
   const int col = G.colbase + ct * TS + t;
   const bool ok = (TS <= 16 || col < G.KXL) && item;
   const unsigned kystride = (unsigned)G.KXP << G.zb_shift;
@@ -898,10 +903,11 @@ __global__ void __launch_bounds__((ZCfg<T, LG, WC>::NT), (ZCfg<T, LG, WC>::WPE))
   const unsigned off = (unsigned)(u >> G.zb_shift) * (unsigned)blk + (unsigned)(u & (ZB - 1)) * G.KXP + col;
   // ky' rows folding onto kyc: ky = kyc and ky = 2 ny - kyc (the same row for kyc = 0 and ny)
   const int nk = (kyc == 0 || kyc == G.ny) ? 1 : 2;
-  const int ntile = nk * G.nc;
+  const int ncl = G.csplit ? 1 : G.nc, c_lo = G.csplit ? G.c0 + k : G.c0;  // components of this workgroup
+  const int ntile = nk * ncl;
   auto tile_base = [&](int it) {
-    const int ky = it < G.nc ? kyc : 2 * G.ny - kyc;
-    const int c = G.c0 + (it < G.nc ? it : it - G.nc);
+    const int ky = it < ncl ? kyc : 2 * G.ny - kyc;
+    const int c = c_lo + (it < ncl ? it : it - ncl);
     const int kyp = (ky & 1) * G.ny + (ky >> 1);
     return buf + (size_t)c * cstride + (size_t)kyp * ZB * G.KXP;
   };
@@ -1263,6 +1269,15 @@ int smi_pruned_greens_download(smi_poisson* p, void* host) {
   return smi_memcpy_d2h(p->ctx, host, p->pruned->green, p->pruned->green_bytes);
 }
 
+// Column launches of fewer workgroups than this give every component its own workgroups: on a small grid the walk
+// over the components inside one workgroup is the longest chain of the launch (64^3: 130 workgroups of six tiles each
+// in the z convolution).  Measured per step: 32^3 71 -> 55 us, 64^3 79 -> 62 us, 128^3 267 -> 262 us with the bound at
+// 2048; at 8192 the z convolution of 256^3 loses 10 % (its workgroups no longer share a Green's table row).
+#ifndef SMI_FFT_SPLIT_BELOW
+#define SMI_FFT_SPLIT_BELOW 2048
+#endif
+constexpr long long kSplitComponentsBelow = SMI_FFT_SPLIT_BELOW;
+
 template <typename T, int LG, int WC>
 static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int colbase, int ncols) {
   G.colbase = colbase;
@@ -1278,7 +1293,8 @@ static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int 
     // one workgroup per (column tile, folded ky), looping over mirror rows and components
     if constexpr (WC == SMI_FFT_ZCOLS) {
       using Cfg = ZCfg<T, LG, WC>;
-      const dim3 grid = grid_for(Cfg::TS, Cfg::PF, G.ny + 1, 1);
+      G.csplit = G.nc > 1 && (long long)((ncols + Cfg::TS - 1) / Cfg::TS) * (G.ny + 1) < kSplitComponentsBelow;
+      const dim3 grid = grid_for(Cfg::TS, Cfg::PF, G.ny + 1, G.csplit ? G.nc : 1);
       SMI_CHECK(set_lds((const void*)k_fft_z_conv<T, LG, WC>, Cfg::BYTES));
       k_fft_z_conv<T, LG, WC><<<grid, Cfg::NT, Cfg::BYTES, c->stream>>>((Cx<T>*)s->bufB, (const T*)s->green, G,
                                                                        (const Cx<T>*)s->tw[2]);
@@ -1303,7 +1319,9 @@ static int launch_cols_tiles(smi_ctx* c, PrunedState* s, int which, PGeo G, int 
         }
       }
     }
-    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, (planes + G.zg - 1) / G.zg, 1);
+    G.csplit = G.nc > 1 && (long long)((ncols + Cfg::TS - 1) / Cfg::TS) * ((planes + G.zg - 1) / G.zg) <
+                               kSplitComponentsBelow;
+    const dim3 grid = grid_for(Cfg::TS, Cfg::PF, (planes + G.zg - 1) / G.zg, G.csplit ? G.nc : 1);
     const Cx<T>* tw = (const Cx<T>*)s->tw[1];
     if (which == 0) {
       SMI_CHECK(set_lds((const void*)k_fft_y_fwd<T, LG, WC>, Cfg::BYTES));

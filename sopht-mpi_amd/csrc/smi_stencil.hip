@@ -1764,7 +1764,7 @@ static int fused_zchunk(const smi_ctx* c, int tiles_per_plane, int planes) {
   if (c->opt_fused_zchunk > 0) return c->opt_fused_zchunk < planes ? c->opt_fused_zchunk : planes;
   int best = planes;
   double best_eff = 0.0;
-  for (int n = 1; n == 1 || n * 4 <= planes; ++n) {  // (chunks of 4 planes or more: small grids want workgroups, not long marches)
+  for (int n = 1; n <= planes; ++n) {  // (down to one plane per chunk: small grids want workgroups, not long marches)
     const int zc = (planes + n - 1) / n;
     const long long wgs = (long long)tiles_per_plane * ((planes + zc - 1) / zc);
     const long long rounds = (wgs + n_cu - 1) / n_cu;

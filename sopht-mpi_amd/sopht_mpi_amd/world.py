@@ -91,7 +91,18 @@ class SocketWorld:
         self._peers = {}
         server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        server.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", base + self.rank))
+        host = "0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1"
+        # the port may be held for a moment by somebody's outgoing connection (launchers pick rendezvous ports from
+        # the range the system hands out to clients): try for a while before giving up
+        deadline = time.time() + min(timeout, 20.0)
+        while True:
+            try:
+                server.bind((host, base + self.rank))
+                break
+            except OSError:
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.1)
         server.listen(self.size)
         # connect to every lower rank, accept every higher rank
         for peer in range(self.rank):
