@@ -54,6 +54,35 @@ def _ns_params():
     return out
 
 
+@pytest.mark.parametrize("filt", [False, True])
+@pytest.mark.parametrize("ghost,width", [(2, 0), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2)])
+def test_one_call_step_with_other_penalty_zones(smi, ghost, width, filt):
+    """Inside the one-call step the x bands of the penalisation are applied in the store of the kernel that writes
+    the new vorticity when ghost + zone width = 4 (a band is one 16-byte vector), and by the operator's own x pass
+    otherwise: both against the oracle, with the one-pass filter and without, whole arrays including ghosts."""
+    real_t, n = np.float32, (24 if ghost == 3 else 16, 16, 32)
+    rng = np.random.default_rng(3)
+    kw = dict(with_free_stream_flow=True, filter_vorticity=filt, ghost_size=ghost, penalty_zone_width=width)
+    if filt:
+        kw["filter_setting_dict"] = {"order": 1, "type": "multiplicative"}
+    gpu, cpu = _pair(smi, n, "navier_stokes", real_t, fused_step=True, poisson_backend="rocfft", **kw)
+    # vorticity that reaches the bands, so that the penalisation has something to act on
+    w0 = (0.2 * rng.standard_normal(cpu.vorticity_field.shape)).astype(real_t)
+    gpu.vorticity_field[...] = w0
+    cpu.vorticity_field[...] = w0
+    fs = np.array([0.5, -0.25, 1.0])
+    gpu.compute_flow_velocity(free_stream_velocity=fs)
+    cpu.compute_flow_velocity(free_stream_velocity=fs)
+    for step in range(2):
+        dt = cpu.compute_stable_timestep(dt_prefac=0.25)
+        gpu.time_step(dt=dt, free_stream_velocity=fs)
+        cpu.time_step(dt=dt, free_stream_velocity=fs)
+        assert_close(gpu.vorticity_field.get(), cpu.vorticity_field, real_t, factor=1.0 + 0.5 * step,
+                     what=f"vorticity incl. ghosts, ghost {ghost} width {width} step {step}")
+        assert_close(gpu.velocity_field.get(), cpu.velocity_field, real_t, factor=2.0 + 0.5 * step,
+                     what=f"velocity incl. ghosts, ghost {ghost} width {width} step {step}")
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("real_t", [np.float32, np.float64])
 @pytest.mark.parametrize("n,flow_type,free_stream,filt,backend", _ns_params())
