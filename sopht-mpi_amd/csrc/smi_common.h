@@ -88,6 +88,10 @@ struct smi_ctx {
   int opt_check_forcing_support;
 };
 constexpr int kUmaxSlots = 64;
+// the context's pinned host words (smi_ctx::red_host): 8 doubles for the reductions, kUmaxSlots words for the step's
+// velocity maximum, and from kPinnedStageOffset on a staging area for small host transfers
+constexpr size_t kPinnedStageOffset = 1024, kPinnedStageBytes = 7168, kPinnedBytes = kPinnedStageOffset + kPinnedStageBytes;
+static_assert(sizeof(double) * (8 + kUmaxSlots) <= kPinnedStageOffset, "pinned words overlap");
 
 constexpr int kRedBlocks = 2048;
 

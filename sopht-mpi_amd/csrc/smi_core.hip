@@ -30,7 +30,7 @@ static int ctx_allocate(smi_ctx* c) {
   SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   SMI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
   SMI_CHECK_HIP(hipMalloc(&c->red_partials, sizeof(double) * (kRedBlocks + 8)));
-  SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, sizeof(double) * (8 + kUmaxSlots), hipHostMallocDefault));
+  SMI_CHECK_HIP(hipHostMalloc((void**)&c->red_host, kPinnedBytes, hipHostMallocDefault));
   SMI_CHECK_HIP(hipMalloc(&c->fac_dev, sizeof(double) * 6 * 64));
   SMI_CHECK_HIP(hipMalloc(&c->umax_slots, sizeof(unsigned long long) * kUmaxSlots));
   for (int i = 0; i < 2; ++i) SMI_CHECK_HIP(hipMalloc(&c->halo_recv[i], c->halo_cap));
@@ -270,14 +270,31 @@ extern "C" int smi_free(smi_ctx* c, void* dptr) {
   SMI_CHECK_HIP(hipFree(dptr));
   return 0;
 }
+// Transfers of a few kilobytes (per-frame loads of a body, node counts, scalars) go through the context's pinned
+// host words: a copy from or into pageable memory is staged by the runtime and costs some ten microseconds more, which
+// a loop that reads a handful of small results per step notices.
 extern "C" int smi_memcpy_h2d(smi_ctx* c, void* dst, const void* src, size_t bytes) {
   SMI_REQUIRE(c && dst && src, "smi_memcpy_h2d: null argument");
-  SMI_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  if (bytes <= kPinnedStageBytes) {
+    char* stage = reinterpret_cast<char*>(c->red_host) + kPinnedStageOffset;
+    // (the last transfer staged here has completed: every user of the words synchronises before it returns)
+    memcpy(stage, src, bytes);
+    SMI_CHECK_HIP(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, c->stream));
+  } else {
+    SMI_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  }
   SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
 extern "C" int smi_memcpy_d2h(smi_ctx* c, void* dst, const void* src, size_t bytes) {
   SMI_REQUIRE(c && dst && src, "smi_memcpy_d2h: null argument");
+  if (bytes <= kPinnedStageBytes) {
+    char* stage = reinterpret_cast<char*>(c->red_host) + kPinnedStageOffset;
+    SMI_CHECK_HIP(hipMemcpyAsync(stage, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
+    memcpy(dst, stage, bytes);
+    return 0;
+  }
   SMI_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   SMI_CHECK_HIP(hipStreamSynchronize(c->stream));
   return 0;
