@@ -889,7 +889,8 @@ struct TileLane {
   long long q, hq;   // plane offsets of the own vector and of the halo vector
   int own_off, h_off;  // LDS offsets within one component tile
 };
-__device__ __forceinline__ TileLane tile_lane(const Geo& G, const TileShape& S, const Blk& B) {
+// corners: the rows below / above run one vector further on either side (kernels whose stencil reaches diagonally)
+__device__ __forceinline__ TileLane tile_lane(const Geo& G, const TileShape& S, const Blk& B, bool corners = false) {
   TileLane L;
   const int tyi = B.x / S.ntx, txi = B.x - tyi * S.ntx;
   const int tid = threadIdx.x;
@@ -901,10 +902,11 @@ __device__ __forceinline__ TileLane tile_lane(const Geo& G, const TileShape& S, 
   L.own = ly < S.ty && L.y < G.py && L.x0 < G.px;
   L.q = L.own ? (long long)L.y * G.px + L.x0 : 0;
   L.own_off = L.own ? (ly + 1) * S.pitch + 4 + 4 * lx : spare;
-  const int nrow = 2 * S.txl, ntask = nrow + 2 * S.ty;
+  const int rowl = S.txl + (corners ? 2 : 0), first = corners ? -1 : 0;  // vectors per halo row, the first one
+  const int nrow = 2 * rowl, ntask = nrow + 2 * S.ty;
   int hy, hx, off;
   if (tid < nrow) {
-    const int top = tid >= S.txl, hl = tid - top * S.txl;
+    const int top = tid >= rowl, hl = tid - top * rowl + first;
     hy = top ? ty0 + S.ty : ty0 - 1;
     hx = tx0 + 4 * hl;
     off = (top ? S.ty + 1 : 0) * S.pitch + 4 + 4 * hl;
@@ -1314,6 +1316,106 @@ __global__ void __launch_bounds__(kBlock) k_filter_fused(T* __restrict__ out, co
     cur = nxt;
   }
   for (int z = ze + 1; z < z1; ++z) put(z, ld<T, V>(f + z * G.plane));
+}
+
+// k_filter_fused on the 16-byte path with the LDS tiling of k_diffuse_tiled: the plane whose F2 = Ly(Lx f) is due sits
+// in one of two LDS tiles (own cells and a ring of one cell, corners included: F2 reaches diagonally), F2 of the
+// planes behind, at and ahead and f of the plane being written stay in registers.  The non-tiled form reads three
+// rows and six scalars per plane and lane through the L1; this one reads each cell of the plane once per tile.
+// The arithmetic, masks and their order are those of k_filter_fused.  Grid z = component.
+template <typename T>
+__global__ void __launch_bounds__(kTileThreads) k_filter_tiled(T* __restrict__ out, const T* __restrict__ f, Geo G,
+                                                              int zchunk, TileShape S, int zlo_e, int zhi_e,
+                                                              PenX<T> X) {
+  extern __shared__ char smi_tile_smem[];
+  T* lds = reinterpret_cast<T*>(smi_tile_smem);
+  const Blk B = xcd_block<true>();
+  const TileLane L = tile_lane(G, S, B, true);
+  out += (long long)B.z * G.vol;
+  f += (long long)B.z * G.vol;
+  const int comp = (S.rows + 2) * S.pitch;
+  bool xc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) xc[e] = in_core_x(G, L.x0 + e);
+  const bool yc = L.own && in_core_y(G, L.y);
+  const int ylo_e = G.ylo_c - (G.yf_lo >= 0 ? 1 : 0), yhi_e = G.yhi_c + (G.yf_hi >= 0 ? 1 : 0);
+  const bool ycm = L.y - 1 >= ylo_e && L.y - 1 <= yhi_e, ycp = L.y + 1 >= ylo_e && L.y + 1 <= yhi_e;
+  const int band = (X.on_lo && L.x0 == 0) ? 1 : ((X.on_hi && L.x0 == G.px - 4) ? 2 : 0);
+  auto put = [&](int z, Pack<T, 4> o) {
+    pen_x_apply(o, band, X);
+    if (L.own) st<T, 4>(out + z * G.plane + L.q, o);
+  };
+  const int z0 = B.y * zchunk, z1 = min(z0 + zchunk, G.pz);
+  const int zs = max(z0, G.zlo_c), ze = min(z1 - 1, G.zhi_c);
+  const bool run = zs <= ze;  // uniform over the workgroup
+  const T* fo = f + L.q;
+  const T* fh = f + L.hq;
+  for (int z = z0; z < (run ? zs : z1); ++z) put(z, ld<T, 4>(fo + z * G.plane));
+  if (!run) return;
+  // Lx of the row at `row` of the LDS tile (masked to the row's cells inside D), then F2 of the plane in tile `buf`
+  auto lx_row = [&](const T* row, bool row_in_core) {
+    Pack<T, 4> r = zero_pack<T, 4>();
+    if (!row_in_core) return r;
+    const Pack<T, 4> c = ld<T, 4>(row);
+    const T xm = row[-1], xp = row[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const T left = e == 0 ? xm : c.v[e - 1], right = e == 3 ? xp : c.v[e + 1];
+      r.v[e] = xc[e] ? T(0.25) * (-right - left + T(2) * c.v[e]) : T(0);
+    }
+    return r;
+  };
+  auto f2_tile = [&](int buf, int zp) {
+    Pack<T, 4> r = zero_pack<T, 4>();
+    if (zp < zlo_e || zp > zhi_e) return r;  // uniform
+    const T* tc = lds + buf * comp + L.own_off;
+    const Pack<T, 4> a = lx_row(tc - S.pitch, ycm), b = lx_row(tc, true), c = lx_row(tc + S.pitch, ycp);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = xc[e] ? T(0.25) * (-c.v[e] - a.v[e] + T(2) * b.v[e]) : T(0);
+    return r;
+  };
+  // The tile holds plane w = z + 1 while plane z is written: w runs from zs - 1 (two steps that only form F2) to
+  // ze + 1.  Planes rotate through four register sets and the halo through two by the argument order of step(), as
+  // in k_diffuse_tiled; the loads of plane w + 2 are issued at the top of step w.
+  auto plane = [&](int z) { return (long long)min(max(z, 0), G.pz - 1) * G.plane; };
+  const int w0 = zs - 1;
+  Pack<T, 4> pa = ld<T, 4>(fo + plane(w0 - 1)), pb = ld<T, 4>(fo + plane(w0));
+  Pack<T, 4> pc = ld<T, 4>(fo + plane(w0 + 1)), pd, ha = ld<T, 4>(fh + plane(w0 + 1)), hb;
+  st<T, 4>(lds + (w0 & 1) * comp + L.own_off, pb);
+  st<T, 4>(lds + (w0 & 1) * comp + L.h_off, ld<T, 4>(fh + plane(w0)));
+  Pack<T, 4> f2p = zero_pack<T, 4>(), f2c = zero_pack<T, 4>();
+  auto step = [&](int w, const Pack<T, 4>& prev, const Pack<T, 4>& nxt, Pack<T, 4>& nxt2, const Pack<T, 4>& h1,
+                  Pack<T, 4>& h2) {
+    nxt2 = ld<T, 4>(fo + plane(w + 2));  // in flight across this step
+    h2 = ld<T, 4>(fh + plane(w + 2));
+    __syncthreads();
+    const int buf = w & 1;
+    const Pack<T, 4> f2n = f2_tile(buf, w);
+    const int z = w - 1;
+    if (z >= zs) {  // uniform
+      Pack<T, 4> o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const T flux = (yc && xc[e]) ? T(0.25) * (-f2n.v[e] - f2p.v[e] + T(2) * f2c.v[e]) : T(0);
+        o.v[e] = prev.v[e] - flux;
+      }
+      put(z, o);
+    }
+    f2p = f2c;
+    f2c = f2n;
+    st<T, 4>(lds + (buf ^ 1) * comp + L.own_off, nxt);
+    st<T, 4>(lds + (buf ^ 1) * comp + L.h_off, h1);
+  };
+  for (int w = w0; w <= ze + 1; w += 4) {
+    step(w, pa, pc, pd, ha, hb);
+    if (w + 1 > ze + 1) break;
+    step(w + 1, pb, pd, pa, hb, ha);
+    if (w + 2 > ze + 1) break;
+    step(w + 2, pc, pa, pb, ha, hb);
+    if (w + 3 > ze + 1) break;
+    step(w + 3, pd, pb, pc, hb, ha);
+  }
+  for (int z = ze + 1; z < z1; ++z) put(z, ld<T, 4>(fo + z * G.plane));
 }
 
 // zero the outer (g + width) layers next to physical faces (zero_bands of the wrappers)
@@ -2006,8 +2108,12 @@ int smi_filter_apply_impl(smi_ctx* c, void* out, void* in, int ncomp, const doub
         }
         *pen_done = 1;
       }
-      LaunchShape s = plan<4>(c, ncomp);
-      k_filter_fused<T, 4><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e, X);
+      // (chunks of 16 planes like the other tiled kernels: 8, 32 and 64 measured 0.351, 0.360, 0.393 against 0.344 ms
+      // at 384^3, although every chunk forms F2 of two planes before it writes its first one)
+      const TiledLaunch t = tiled_launch<T>(c, 1, ncomp);
+      SMI_CHECK(allow_lds(k_filter_tiled<T>));
+      k_filter_tiled<T><<<t.grid, t.threads, t.lds_bytes, c->stream>>>((T*)out, (const T*)in, G, t.zchunk, t.S, zlo_e,
+                                                                       zhi_e, X);
     } else {
       LaunchShape s = plan<1>(c, ncomp);
       k_filter_fused<T, 1><<<s.grid, kBlock, 0, c->stream>>>((T*)out, (const T*)in, G, s.zchunk, zlo_e, zhi_e, X);
