@@ -72,7 +72,7 @@ int smi_ctx_wait_for(smi_ctx* waiter, smi_ctx* other);
  *   "fused_zchunk"            (SMI_FUSED_ZCHUNK)             planes per workgroup of the one-pass kernel, 0 = automatic
  *   "check_forcing_support"   (SMI_CHECK_FORCING_SUPPORT)    1: the step verifies a promised forcing box before use
  *   "transpose_chunks"        (SMI_FFT_TRANSPOSE_CHUNKS)     1, 2 or 4 z chunks per spectral transpose across ranks
- *                                                            (default: 2 from eight ranks on, 1 below) */
+ *                                                            (default: 1) */
 int smi_ctx_set_option(smi_ctx* ctx, const char* name, int value);
 int smi_ctx_get_option(smi_ctx* ctx, const char* name, int* value);
 

@@ -112,10 +112,11 @@ static int ctx_create(smi_ctx** out, int device, int dtype, int nz, int ny, int 
   c->opt_split_launch = getenv("SMI_FUSED_SPLIT_LAUNCH") != nullptr;
   c->opt_check_forcing_support = getenv("SMI_CHECK_FORCING_SUPPORT") != nullptr;
   if (const char* e = getenv("SMI_FUSED_ZCHUNK")) c->opt_fused_zchunk = atoi(e) > 0 ? atoi(e) : 32;
-  // Two chunks per transpose from eight ranks on: there the transforms and the link time of a step are about equal
-  // and what is exposed is the first forward and the last backward transpose, which chunking halves; with fewer
-  // ranks the links are the bound by a wide margin and chunks only add RCCL groups.
-  c->opt_transpose_chunks = nranks >= 8 ? 2 : 1;
+  // One chunk per transpose unless asked otherwise.  At eight ranks two chunks halve what is exposed of the first
+  // forward and the last backward transpose (about 0.15 ms of a 2 ms step at 512^3) and cost 0.09 ms of shorter
+  // launches, a margin that rests on RCCL groups being cheap, which no multi-GPU node was at hand to measure; with
+  // fewer ranks the links are the bound by a wide margin and chunks only add groups.
+  c->opt_transpose_chunks = 1;
   if (const char* e = getenv("SMI_FFT_TRANSPOSE_CHUNKS")) {
     const int n = atoi(e);
     SMI_REQUIRE(n == 1 || n == 2 || n == 4, "SMI_FFT_TRANSPOSE_CHUNKS=%s: must be 1, 2 or 4", e);
